@@ -1,0 +1,170 @@
+/*
+ * mpopis.h -- C ABI of the MI355X-native MPPI/MPOPI sampling engine (libmpopis_hip.so).
+ *
+ * Drop-in boundary for the rollout-and-reweight hot path of sisl/MPOPIS
+ * (src/mppi_mpopi_policies.jl).  The reference has NO FFI; its plug-in seam is Julia dispatch on
+ * (policy type, env type) -- it already specialises these three functions for EnvpoolEnv
+ * (src/mppi_mpopi_policies.jl:148,240; src/utils.jl:103).  Each entry point below replaces the
+ * reference interface cited next to it; julia/MPOPISHip.jl and INTEGRATION.md show the ccall
+ * methods a maintainer adds.  All file:line citations are relative to the reference repo root.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, FP64 everywhere (the reference hard-codes Float64,
+ *     src/mppi_mpopi_policies.jl:3-5,13,110-111), Julia column-major layouts, no repacking.
+ *   - a handle owns B = cfg.batch independent "trial slots" (independent env + policy pairs =
+ *     the `for k in 1:num_trials` axis of src/examples/car_example.jl:170); every array argument
+ *     is the concatenation over slots b = 0..B-1 of the per-trial reference array.
+ *   - the caller owns all host arrays; the library copies in/out during the call and never
+ *     retains host pointers.  Calls are synchronous (return after the stream has drained).
+ *   - return 0 on success; negative codes mirror the reference's error()/exception sites:
+ *       MPOPIS_ERR_ARG     (-1) size/argument errors     src/mppi_mpopi_policies.jl:55,64,73,79-80
+ *       MPOPIS_ERR_NOT_PD  (-2) PosDefException from MvNormal(Sigma')   :447,551,723,796
+ *       MPOPIS_ERR_ACTION  (-3) "Action is not in action space" / NaN   src/envs/car_racing.jl:239
+ *       MPOPIS_ERR_HIP     (-4) HIP runtime failure / no device
+ *     mpopis_last_error() returns a human readable message for the last failure.
+ *   - a handle is not thread-safe; distinct handles are independent (own HIP stream).
+ */
+#ifndef MPOPIS_H
+#define MPOPIS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPOPIS_ABI_VERSION 1
+
+enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4 };
+
+/* env kinds: RL.jl MountainCarEnv(continuous=true) + src/examples/mountaincar_example.jl:4-22;
+ * CarRacingEnv src/envs/car_racing.jl (num_cars==1) / MultiCarRacingEnv src/envs/multi-car_racing.jl */
+enum { MPOPIS_ENV_MOUNTAINCAR = 0, MPOPIS_ENV_CAR = 1 };
+
+/* policy kinds = get_policy symbols, src/examples/example_utils.jl:20-128 */
+enum { MPOPIS_POL_MPPI = 0,            /* :mppi       MPPI_Policy      :107-216 */
+       MPOPIS_POL_GMPPI = 1,           /* :gmppi      GMPPI_Policy     :284-315 */
+       MPOPIS_POL_IMPPI = 2,           /* :imppi      IMPPI_Policy     :321-373 */
+       MPOPIS_POL_CEMPPI = 3,          /* :cemppi     CEMPPI_Policy    :379-472 */
+       MPOPIS_POL_CMAMPPI = 4,         /* :cmamppi    CMAMPPI_Policy   :478-606 */
+       MPOPIS_POL_MUAISMPPI = 5,       /* :μaismppi   μAISMPPI_Policy  :612-671 */
+       MPOPIS_POL_MUSIGMAAISMPPI = 6,  /* :μΣaismppi  μΣAISMPPI_Policy :677-742 */
+       MPOPIS_POL_PMCMPPI = 7 };       /* :pmcmppi    PMCMPPI_Policy   :748-817 */
+
+enum { MPOPIS_SIGMA_EST_MLE = 0, MPOPIS_SIGMA_EST_SS = 1 };   /* CEMPPI Σ_est :414-426 */
+
+/* Car parameter vector (20 doubles) = CarRacingEnvParams fields in declaration order
+ * (src/envs/car_racing.jl:2-21) followed by dt, δt (:33-34).  MountainCar: 8 doubles
+ * {min_pos,max_pos,max_speed,goal_pos,goal_velocity,power,gravity,max_steps}. */
+#define MPOPIS_CAR_NPARAMS 20
+#define MPOPIS_MOUNTAINCAR_NPARAMS 8
+
+typedef struct mpopis_handle mpopis_handle;
+
+/* Mirrors the keyword arguments of MPPI_Policy_Params (:36-47) and of the per-policy
+ * constructors (:337-340,:407-412,:506-511,:630-634,:695-699,:766-770). */
+typedef struct {
+    int32_t device;            /* HIP device ordinal                                              */
+    int32_t env_kind;          /* MPOPIS_ENV_*                                                    */
+    int32_t num_cars;          /* car env: 1 => CarRacingEnv, >1 => MultiCarRacingEnv(N)          */
+    int32_t policy;            /* MPOPIS_POL_*                                                    */
+    int32_t num_samples;       /* K                                                               */
+    int32_t horizon;           /* H (T in the reference code)                                     */
+    int32_t batch;             /* B resident independent trials                                   */
+    int32_t ais_its;           /* opt_its / ais_its N (ignored for :mppi/:gmppi)                  */
+    int32_t sigma_est;         /* MPOPIS_SIGMA_EST_* (:cemppi)                                    */
+    int32_t log_trajectories;  /* params.log: keep K x H x ss model trajectories (MPPI_Logger)   */
+    double lambda;             /* λ                                                               */
+    double alpha;              /* α ; γ = λ(1-α)                                                  */
+    double lambda_ais;         /* λ_ais (:μaismppi/:μΣaismppi/:pmcmppi)                           */
+    double elite_threshold;    /* ce_elite_threshold / elite_perc_threshold                       */
+    double cma_sigma;          /* σ (:cmamppi)                                                    */
+    uint64_t seed;             /* trial slot b draws from seed+b+1 (seed!(pol, seed+k), car_example.jl:188) */
+} mpopis_config;
+
+/* Injected randomness for results-parity runs (NULL => device Philox4x32-10 streams).
+ * The reference draws from Julia's MersenneTwister, which is not reproduced; parity is defined
+ * on identical standard normals / resampling draws. */
+typedef struct {
+    const double *Z;        /* G-variants: B x N x (cs x K col-major randn! matrix, :308,:448,:556,:657,:724,:797)
+                               :mppi: B x (K*T*as), element ((t*K+k)*as+a)  (rand(rng,P,K,T), :193)  */
+    const int32_t *res_i0;  /* :pmcmppi: B x (N-1) x K uniform ints in [0,K) (0-based)  (:805)   */
+    const double *res_u;    /* :pmcmppi: B x (N-1) x K uniforms in [0,1)                          */
+} mpopis_noise;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int  mpopis_abi_version(void);
+const char *mpopis_last_error(const mpopis_handle *h);     /* h may be NULL: last create() error  */
+
+/* XPolicy(env; kwargs...) + env construction: src/mppi_mpopi_policies.jl:116-119,298-301,...;
+ * src/examples/car_example.jl:172-185.  Defaults after create: env params = reference
+ * defaults, track = none (must be set for car envs), bounds = [-1,1], U = 0, Sigma = I. */
+int  mpopis_create(const mpopis_config *cfg, mpopis_handle **out);
+void mpopis_destroy(mpopis_handle *h);
+
+/* ---- env description (the env protocol the path consumes) ------------------------ */
+int  mpopis_set_env_params(mpopis_handle *h, const double *p, int32_t n);   /* env.params, env.dt, env.δt */
+int  mpopis_set_track(mpopis_handle *h, const double *x, const double *y, const double *w, int32_t P);
+                                                                  /* env.track.{x′,y′,lane_width′} car_racing_tracks.jl:21-23 */
+int  mpopis_set_action_bounds(mpopis_handle *h, const double *lo, const double *hi); /* action_space(env) */
+int  mpopis_reset(mpopis_handle *h);                       /* reset!(env) per slot: car_racing.jl:215-223, multi :160-180 */
+int  mpopis_set_state(mpopis_handle *h, const double *x /* B*ss */, const int32_t *t, const int32_t *done);
+int  mpopis_get_state(mpopis_handle *h, double *x /* B*ss */, int32_t *t, int32_t *done);
+
+/* ---- policy state ---------------------------------------------------------------------------- */
+int  mpopis_set_U(mpopis_handle *h, const double *U /* B*cs */);            /* pol.U                */
+int  mpopis_get_U(mpopis_handle *h, double *U /* B*cs */);
+int  mpopis_set_Sigma(mpopis_handle *h, const double *Sigma, int32_t n);    /* pol.Σ : n = as (mppi, or block-replicated :76-78) or cs; col-major, shared by all slots */
+int  mpopis_seed(mpopis_handle *h, uint64_t seed);                          /* seed!(pol, seed) src/MPOPIS.jl:54 */
+
+/* ---- Level 1: simulate_model(pol, env, E, Σ_inv, U_orig) -> trajectory_cost  (:261-278) ------
+ * x0: B*ss (NULL: resident env state); U: B*cs current AIS mean (pol.U); U_orig: B*cs (NULL => U);
+ * E: B x (cs x K col-major); Sigma_inv: cs x cs col-major or NULL (required only when γ != 0);
+ * cost: B*K out. */
+int  mpopis_rollout_costs(mpopis_handle *h, const double *x0, const double *U, const double *U_orig,
+                          const double *E, const double *Sigma_inv, double *cost);
+
+/* ---- Level 2: control = pol(env)  (:121-146 for :mppi, :221-238 for the G-variants) ------------
+ * Runs calculate_trajectory_costs for the configured policy, the weighted control update and
+ * get_controls_roll_U! (src/utils.jl:88-101) for every slot.  Resident env state is used (set it
+ * with mpopis_set_state) and pol.U is rolled in place on the device.
+ * Outputs (any may be NULL): control B*as; cost B*K; weights B*K; E_out B x (cs x K) after the
+ * final shift (:468,:602,:668,:739,:814) [:mppi: B x K*T*as]; resample_idx0 B x (N-1) x K 0-based;
+ * iters_run B (AIS iterations executed, CE/CMA may break early :459-461,:567-569). */
+int  mpopis_policy_step(mpopis_handle *h, const mpopis_noise *noise,
+                        double *control, double *cost, double *weights, double *E_out,
+                        int32_t *resample_idx0, int32_t *iters_run);
+
+/* env(action) for the resident real envs + reward(env): src/envs/car_racing.jl:238-250,201-213;
+ * multi-car_racing.jl:200-207,145-158; mountaincar_example.jl:4-22.  action B*as, reward B out. */
+int  mpopis_env_step(mpopis_handle *h, const double *action, double *reward);
+
+/* pol.logger.trajectories (src/mppi_mpopi_policies.jl:92-95, src/utils.jl:139-141): B x K x (H x ss),
+ * state after each model step of the LAST simulate_model call; needs cfg.log_trajectories. */
+int  mpopis_get_trajectories(mpopis_handle *h, double *out);
+
+/* ---- Level 3: the closed-loop trial harness, device resident ------------------------------------
+ * simulate_car_racing / simulate_mountaincar trial loop (src/examples/car_example.jl:170-326,
+ * mountaincar_example.jl:125-180) for all B slots at once, device RNG, no host round trips per
+ * MPC step.  One record per slot (MPOPIS_RECORD_LEN doubles):
+ *   [0] rew [1] steps [2] rew/step [3..6] lap_t[1..4] [7] mean_v [8] max_v [9] mean_β [10] max_β
+ *   [11] β_viol [12] T_viol [13] C_viol [14] rollouts executed [15] status            (:144-155,287-302) */
+#define MPOPIS_RECORD_LEN 16
+int  mpopis_run_trials(mpopis_handle *h, int32_t num_steps, int32_t laps, double *records /* B*16 */,
+                       double *actions /* NULL or B x (num_steps+1) x as */);
+
+/* ---- measurement hooks (bench.py; HIP events on the engine's own stream) ----------------------- */
+int  mpopis_timing_enable(mpopis_handle *h, int32_t on);
+/* accumulated since enable/reset: per kernel class average launch duration.
+ * names: semicolon separated list; ms_total[i], launches[i] for i < *n (in: capacity). */
+int  mpopis_timing_read(mpopis_handle *h, char *names, int32_t names_cap, double *ms_total,
+                        int64_t *launches, int32_t *n);
+int  mpopis_timing_reset(mpopis_handle *h);
+
+/* Synthetic-workload entry used by bench.py: run `steps` policy steps (device RNG, resident
+ * state, env not advanced) back to back on the stream; returns wall ms measured with HIP events
+ * around the whole region and the number of model rollouts executed. */
+int  mpopis_bench_policy_steps(mpopis_handle *h, int32_t steps, double *ms, double *rollouts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+// engine.h -- internal declarations shared by the HIP translation units of libmpopis_hip.so.
+//
+// Data layout in HBM (per handle, B trial slots, all FP64 unless noted):
+//   x      [B][ss]        resident real-env state (+ t[B], done[B] int32)
+//   U      [B][cs]        pol.U (nominal control, step-major like the reference)
+//   Ucur   [B][cs]        AIS mean inside calculate_trajectory_costs (pol.U rebinding)
+//   E      [B][cs][K]     noise, ROW-MAJOR BY CONTROL ROW (K fastest).  The reference stores E as
+//                         cs x K column-major (sample k contiguous); here lanes = samples, so the
+//                         transpose makes every rollout-kernel load and every reduction over k
+//                         coalesced.  The C ABI transposes on upload/download.
+//   Sigma  [B][n][n]      proposal covariance, column-major (n = as for :mppi, cs otherwise)
+//   Lchol  [B][n][n]      its lower Cholesky factor
+//   cost, w [B][K]; status[B] int32; misc per-trial scalars.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mpopis.h"
+#include "car_dynamics.h"
+
+namespace mpopis {
+
+constexpr int kMaxCars = 4;
+constexpr int kMaxAs = 2 * kMaxCars;
+
+struct EnvDesc {
+    int kind;        // MPOPIS_ENV_*
+    int ncars;
+    int ss, as;
+    CarParams car;
+    McParams mc;
+    Track track;     // device pointers
+    double lo[kMaxAs], hi[kMaxAs];
+};
+
+// Arguments of the fused rollout kernel (== simulate_model + rollout_model + env step + reward)
+struct RolloutArgs {
+    EnvDesc env;
+    int B, K, T, cs;
+    const double* x0;      // [B][ss]
+    const int* t0;         // [B] (MountainCar step counter) or nullptr
+    const int* done0;      // [B]
+    const double* Ucur;    // [B][cs]
+    const double* Uorig;   // [B][cs]
+    const double* E;       // [B][cs][K]   (G-variants)  /  [B][T*as][K] (:mppi, same thing)
+    const double* gvec;    // [B][cs] = (γ U_orig' Σ_inv) or nullptr when γ == 0
+    double* cost;          // [B][K]
+    double* traj;          // nullptr or [B][K][ss][T] (Julia (T x ss) column-major per sample)
+    const int* active;     // nullptr or [B]: slots with active==0 are skipped (AIS early break)
+};
+
+void launch_rollout(const RolloutArgs& a, hipStream_t s);
+
+// compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
+void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,
+                    int* status, hipStream_t s);
+
+// out[b][r] = Σ_k w[b][k] * (E[b][r][k] + shift[b][r]) / (norm ? Σ_k w : 1)
+void launch_wmean(const double* E, const double* w, const double* shiftA, const double* shiftB,
+                  double* out, int B, int cs, int K, int normalize, const int* active, hipStream_t s);
+
+// functor tail: wc = U + wn; control = clamp(wc[1:as]); roll U (utils.jl:88-101)
+void launch_finalize_env(const double* wn, double* U, double* control, int B, int cs, int as, int T,
+                         const EnvDesc& env, hipStream_t s);
+
+// layout converters between the ABI's cs x K column-major and the engine's [cs][K]
+void launch_transpose_in(const double* src_colmajor, double* dst_rows, int B, int cs, int K, hipStream_t s);
+void launch_transpose_out(const double* src_rows, const double* shiftA, const double* shiftB,
+                          double* dst_colmajor, int B, int cs, int K, hipStream_t s);
+
+// real env step + reward for the resident envs
+void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action,
+                     double* reward, int* status, int B, hipStream_t s);
+
+// kernels_sample.hip
+void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
+                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s);
+void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                                  const int* active, hipStream_t s);
+void launch_trmm_LZ(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
+
+// kernels_linalg.hip
+void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s);
+void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
+void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
+int wcov_num_tiles(int cs);
+size_t wcov_workspace_doubles(int B, int cs, int ksplit);
+void launch_wcov(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
+                 int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s);
+void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
+                        const int* active, hipStream_t s);
+
+}  // namespace mpopis

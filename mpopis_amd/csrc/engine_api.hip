@@ -1,0 +1,515 @@
+// engine_api.hip -- handle, device buffers, launch sequences and the C ABI of include/mpopis.h.
+//
+// One handle = B resident independent trials (env + policy pairs).  Every policy step is a fixed
+// sequence of kernel launches on the handle's stream; data-dependent control flow of the
+// reference (CE/CMA early break :459-461,:567-569, PosDefException) is turned into per-slot
+// `active` predicates evaluated on the device, so a step never needs a host round trip.
+#include "engine.h"
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+using namespace mpopis;
+
+static std::string g_create_error;
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[512];                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (h) (h)->err = buf_; else g_create_error = buf_;                                 \
+            return MPOPIS_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+#include "engine_handle.h"
+
+// ---- tiny utility kernels -----------------------------------------------------------------------
+__global__ void k_fill_i32(int* p, int v, size_t n) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_copy_f64(const double* s, double* d, size_t n) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) d[i] = s[i]; }
+__global__ void k_bcast_f64(const double* s, double* d, size_t n, int B) {     // d[b][i] = s[i]
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n) for (int b = 0; b < B; ++b) d[(size_t)b * n + i] = s[i];
+}
+__global__ void k_axpy_active(const double* x, double* y, const double* alpha, int n, const int* active) {   // y[b] += alpha[b]*x[b]
+    const int b = blockIdx.y; if (active && !active[b]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
+    const double a = alpha ? alpha[b] : 1.0;
+    y[(size_t)b * n + i] = y[(size_t)b * n + i] + a * x[(size_t)b * n + i];
+}
+__global__ void k_set_iters(int* iters, int n, const int* active, int B) { int b = blockIdx.x * 256 + threadIdx.x; if (b < B && (!active || active[b])) iters[b] = n; }
+
+static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
+static void copy_f64(const double* s_, double* d, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_copy_f64, dim3((n + 255) / 256), dim3(256), 0, s, s_, d, n); }
+
+template <class T> static int dalloc(mpopis_handle* h, T** p, size_t n) {
+    HIPCHK(h, hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    HIPCHK(h, hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream));
+    h->allocs.push_back((void*)*p);
+    return 0;
+}
+
+void mpopis_handle::time_begin(int slot) {
+    if (!timing || ev_used + 2 > (int)events.size()) return;
+    (void)hipEventRecord(events[ev_used], stream);
+    ev_slot.push_back(slot);
+}
+void mpopis_handle::time_end() {
+    if (!timing || ev_used + 2 > (int)events.size()) return;
+    (void)hipEventRecord(events[ev_used + 1], stream);
+    ev_used += 2;
+}
+
+static int sync_status(mpopis_handle* h) {
+    HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    int st = 0;
+    for (int b = 0; b < h->B; ++b) st = std::min(st, h->h_status[b]);
+    if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
+    else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
+    return st;
+}
+
+// ---- ABI ---------------------------------------------------------------------------------------
+extern "C" {
+
+int mpopis_abi_version(void) { return MPOPIS_ABI_VERSION; }
+
+const char* mpopis_last_error(const mpopis_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static void default_car_params(double* p) {      // src/envs/car_racing.jl:68-93
+    const double d2r = M_PI / 180.0;
+    const double v[20] = {2000.0, 3764.0, 0.3, 1.53, 1.23, 241.0, 25.1, 150000.0, 280000.0, 0.9, 0.9, 18.0 * d2r, 90.0 * d2r,
+                          7200.0, 22500.0, 0.6, 0.0, 45.0 * d2r, 0.1, 0.01};
+    memcpy(p, v, sizeof v);
+}
+static void default_mc_params(double* p) {       // RL.jl MountainCarEnvParams, continuous=true
+    const double v[8] = {-1.2, 0.6, 0.07, 0.45, 0.0, 0.0015, 0.0025, 200.0};
+    memcpy(p, v, sizeof v);
+}
+
+int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
+    if (!cfg || !out) { g_create_error = "null argument"; return MPOPIS_ERR_ARG; }
+    *out = nullptr;
+    const bool car = cfg->env_kind == MPOPIS_ENV_CAR;
+    if (!(car || cfg->env_kind == MPOPIS_ENV_MOUNTAINCAR)) { g_create_error = "unknown env kind"; return MPOPIS_ERR_ARG; }
+    if (car && (cfg->num_cars < 1 || cfg->num_cars > kMaxCars)) { g_create_error = "num_cars must be 1..4"; return MPOPIS_ERR_ARG; }
+    if (cfg->policy < MPOPIS_POL_MPPI || cfg->policy > MPOPIS_POL_PMCMPPI) { g_create_error = "No policy_type of that kind"; return MPOPIS_ERR_ARG; }
+    if (cfg->num_samples < 1 || cfg->horizon < 1 || cfg->batch < 1) { g_create_error = "num_samples, horizon, batch must be >= 1"; return MPOPIS_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (the engine has no CPU fallback)"; return MPOPIS_ERR_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "bad device ordinal"; return MPOPIS_ERR_ARG; }
+    mpopis_handle* h = new mpopis_handle();
+    h->cfg = *cfg;
+    HIPCHK((mpopis_handle*)nullptr, hipSetDevice(cfg->device));
+    HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
+    h->as = car ? 2 * cfg->num_cars : 1;
+    h->ss = car ? 8 * cfg->num_cars : 2;
+    h->cs = h->as * h->T;
+    h->N = (cfg->policy == MPOPIS_POL_MPPI || cfg->policy == MPOPIS_POL_GMPPI) ? 1 : std::max(1, cfg->ais_its);
+    h->gamma = cfg->lambda * (1 - cfg->alpha);
+    h->env.kind = cfg->env_kind; h->env.ncars = car ? cfg->num_cars : 0; h->env.ss = h->ss; h->env.as = h->as;
+    double p[20];
+    default_car_params(p); h->env.car = make_car_params(p);
+    default_mc_params(p); h->env.mc = make_mc_params(p);
+    for (int i = 0; i < kMaxAs; ++i) { h->env.lo[i] = -1.0; h->env.hi[i] = 1.0; }
+    h->env.track = Track{nullptr, nullptr, nullptr, 0};
+    const int B = h->B, K = h->K, cs = h->cs;
+    const size_t nn = (size_t)cs * cs;
+    int rc = 0;
+    rc |= dalloc(h, &h->d_x, (size_t)B * h->ss); rc |= dalloc(h, &h->d_t, B); rc |= dalloc(h, &h->d_done, B);
+    rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
+    rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
+    rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
+    rc |= dalloc(h, &h->d_Z, (size_t)B * cs * K); rc |= dalloc(h, &h->d_E, (size_t)B * cs * K);
+    rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);
+    rc |= dalloc(h, &h->d_wn, (size_t)B * cs); rc |= dalloc(h, &h->d_mu, (size_t)B * cs); rc |= dalloc(h, &h->d_gvec, (size_t)B * cs);
+    rc |= dalloc(h, &h->d_dscale, (size_t)B * cs); rc |= dalloc(h, &h->d_dscale0, (size_t)cs);
+    rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B);
+    rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
+    rc |= dalloc(h, &h->d_seeds, B);
+    rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
+    rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K);
+    rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
+    h->ksplit = std::max(1, std::min(16, K / 256));
+    rc |= dalloc(h, &h->d_part, wcov_workspace_doubles(B, cs, h->ksplit));
+    rc |= dalloc(h, &h->d_cma, (size_t)B * (3 * cs + 8)); rc |= dalloc(h, &h->d_cma_ws, (size_t)K);
+    rc |= dalloc(h, &h->d_C, (size_t)B * nn); rc |= dalloc(h, &h->d_Y, (size_t)B * nn); rc |= dalloc(h, &h->d_Tm, (size_t)B * nn);
+    if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
+    if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    h->h_status.assign(B, 0);
+    // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
+    std::vector<double> eye(nn, 0.0);
+    for (int i = 0; i < cs; ++i) eye[(size_t)i * cs + i] = 1.0;
+    if (mpopis_set_Sigma(h, eye.data(), cs) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    if (mpopis_seed(h, cfg->seed) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    if (mpopis_reset(h) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    if (cfg->policy == MPOPIS_POL_CMAMPPI) h->init_cma_constants();
+    if (cfg->policy == MPOPIS_POL_CEMPPI) h->m_elite = (int)nearbyint(K * (1 - cfg->elite_threshold));   // :437
+    *out = h;
+    return MPOPIS_OK;
+}
+
+void mpopis_destroy(mpopis_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto e : h->events) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int mpopis_set_env_params(mpopis_handle* h, const double* p, int32_t n) {
+    if (!h || !p) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR) {
+        if (n != MPOPIS_CAR_NPARAMS) { h->err = "car env expects 20 parameters"; return MPOPIS_ERR_ARG; }
+        h->env.car = make_car_params(p);
+    } else {
+        if (n != MPOPIS_MOUNTAINCAR_NPARAMS) { h->err = "MountainCar expects 8 parameters"; return MPOPIS_ERR_ARG; }
+        h->env.mc = make_mc_params(p);
+    }
+    return MPOPIS_OK;
+}
+
+int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const double* w, int32_t P) {
+    if (!h || !x || !y || !w || P < 2) { if (h) h->err = "bad track"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    double* d = nullptr;
+    if (dalloc(h, &d, (size_t)3 * P)) return MPOPIS_ERR_HIP;
+    HIPCHK(h, hipMemcpyAsync(d, x, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + P, y, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d + 2 * P, w, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->env.track = Track{d, d + P, d + 2 * P, P};
+    return MPOPIS_OK;
+}
+
+int mpopis_set_action_bounds(mpopis_handle* h, const double* lo, const double* hi) {
+    if (!h || !lo || !hi) return MPOPIS_ERR_ARG;
+    for (int i = 0; i < h->as; ++i) { h->env.lo[i] = lo[i]; h->env.hi[i] = hi[i]; }
+    return MPOPIS_OK;
+}
+
+int mpopis_reset(mpopis_handle* h) {
+    if (!h) return MPOPIS_ERR_ARG;
+    std::vector<double> x((size_t)h->B * h->ss, 0.0);
+    for (int b = 0; b < h->B; ++b) {
+        double* s = x.data() + (size_t)b * h->ss;
+        if (h->env.kind == MPOPIS_ENV_CAR) {
+            for (int c = 0; c < h->env.ncars; ++c) {            // car_racing.jl:215-223; multi-car_racing.jl:160-180
+                const int ii = c + 1;
+                if (ii >= 2) s[8 * c] = (ii % 2 == 0) ? (ii / 2.0 * 5.0) : ((1 - ii) / 2.0 * 5.0);
+                s[8 * c + 2] = 90.0 * (M_PI / 180.0);
+                s[8 * c + 3] = 10.0;
+            }
+        } else { s[0] = -0.5; s[1] = 0.0; }                     // reference: x ~ U(-0.6,-0.4) from an unseeded RNG
+    }
+    std::vector<int> z(h->B, 0);
+    return mpopis_set_state(h, x.data(), z.data(), z.data());
+}
+
+int mpopis_set_state(mpopis_handle* h, const double* x, const int32_t* t, const int32_t* done) {
+    if (!h || !x) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * h->B * h->ss, hipMemcpyHostToDevice, h->stream));
+    if (t) HIPCHK(h, hipMemcpyAsync(h->d_t, t, sizeof(int) * h->B, hipMemcpyHostToDevice, h->stream));
+    if (done) HIPCHK(h, hipMemcpyAsync(h->d_done, done, sizeof(int) * h->B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+
+int mpopis_get_state(mpopis_handle* h, double* x, int32_t* t, int32_t* done) {
+    if (!h) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (x) HIPCHK(h, hipMemcpyAsync(x, h->d_x, sizeof(double) * h->B * h->ss, hipMemcpyDeviceToHost, h->stream));
+    if (t) HIPCHK(h, hipMemcpyAsync(t, h->d_t, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+
+int mpopis_set_U(mpopis_handle* h, const double* U) {
+    if (!h || !U) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_U, U, sizeof(double) * h->B * h->cs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+int mpopis_get_U(mpopis_handle* h, double* U) {
+    if (!h || !U) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(U, h->d_U, sizeof(double) * h->B * h->cs, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+
+// MPPI_Policy_Params Σ handling :66-81 : an as x as cov_mat is block-replicated (block_diagm, utils.jl:9-21);
+// for :mppi the as x as Σ is kept by the reference, which is the same distribution as the
+// block-diagonal cs x cs one used here (Cholesky of a block-diagonal matrix is block-diagonal).
+int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
+    if (!h || !Sigma) return MPOPIS_ERR_ARG;
+    const int cs = h->cs, as = h->as;
+    std::vector<double> full((size_t)cs * cs, 0.0);
+    if (n == as && !(n == cs && h->cfg.policy != MPOPIS_POL_MPPI && as == cs)) {
+        for (int t = 0; t < h->T; ++t)
+            for (int j = 0; j < as; ++j)
+                for (int i = 0; i < as; ++i) full[(size_t)(t * as + i) + (size_t)(t * as + j) * cs] = Sigma[i + (size_t)j * as];
+    } else if (n == cs && h->cfg.policy != MPOPIS_POL_MPPI) {
+        memcpy(full.data(), Sigma, sizeof(double) * cs * cs);
+    } else { h->err = "Covariance matrix size problem"; return MPOPIS_ERR_ARG; }     // :79
+    bool diag = true;
+    for (int j = 0; j < cs && diag; ++j) for (int i = 0; i < cs; ++i) if (i != j && full[(size_t)i + (size_t)j * cs] != 0.0) { diag = false; break; }
+    std::vector<double> ds(cs, 0.0);
+    if (diag) for (int i = 0; i < cs; ++i) { const double v = full[(size_t)i + (size_t)i * cs]; if (!(v > 0.0)) { h->err = "PosDefException: Sigma"; return MPOPIS_ERR_NOT_PD; } ds[i] = sqrt(v); }
+    h->sigma_diag = diag;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_Sigma0, full.data(), sizeof(double) * cs * cs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_dscale0, ds.data(), sizeof(double) * cs, hipMemcpyHostToDevice, h->stream));
+    // factor once: L0 (shared by all slots; the reference refactors the same Σ every call, :307)
+    fill_i32(h->d_status, 0, h->B, h->stream);
+    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream);
+    HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->h_status[0] != 0) { h->err = "PosDefException: Sigma is not positive definite"; return MPOPIS_ERR_NOT_PD; }
+    return MPOPIS_OK;
+}
+
+int mpopis_seed(mpopis_handle* h, uint64_t seed) {
+    if (!h) return MPOPIS_ERR_ARG;
+    std::vector<uint64_t> s(h->B);
+    for (int b = 0; b < h->B; ++b) s[b] = seed + (uint64_t)b + 1;              // seed!(pol, seed + k), car_example.jl:188
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_seeds, s.data(), sizeof(uint64_t) * h->B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->mpc_step = 0;
+    return MPOPIS_OK;
+}
+
+int mpopis_rollout_costs(mpopis_handle* h, const double* x0, const double* U, const double* U_orig, const double* E,
+                         const double* Sigma_inv, double* cost) {
+    if (!h || !U || !E || !cost) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    if (h->gamma != 0.0 && !Sigma_inv) { h->err = "Sigma_inv required when alpha != 1"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, K = h->K, cs = h->cs;
+    if (x0) HIPCHK(h, hipMemcpyAsync(h->d_x, x0, sizeof(double) * B * h->ss, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_Ucur, U, sizeof(double) * B * cs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_Uin, U_orig ? U_orig : U, sizeof(double) * B * cs, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_Z, E, sizeof(double) * B * cs * K, hipMemcpyHostToDevice, h->stream));
+    launch_transpose_in(h->d_Z, h->d_E, B, cs, K, h->stream);
+    const double* gv = nullptr;
+    if (h->gamma != 0.0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_tmpS, Sigma_inv, sizeof(double) * cs * cs, hipMemcpyHostToDevice, h->stream));
+        launch_gvec_from_inv(h->d_tmpS, h->d_Uin, h->gamma, h->d_gvec, B, cs, h->stream);
+        gv = h->d_gvec;
+    }
+    fill_i32(h->d_status, 0, B, h->stream);
+    h->rollout(h->d_Ucur, h->d_Uin, gv, nullptr);
+    HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return MPOPIS_OK;
+}
+
+int mpopis_env_step(mpopis_handle* h, const double* action, double* reward) {
+    if (!h || !action) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_control, action, sizeof(double) * h->B * h->as, hipMemcpyHostToDevice, h->stream));
+    fill_i32(h->d_status, 0, h->B, h->stream);
+    launch_env_step(h->env, h->d_x, h->d_t, h->d_done, h->d_control, h->d_reward, h->d_status, h->B, h->stream);
+    if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, sizeof(double) * h->B, hipMemcpyDeviceToHost, h->stream));
+    return sync_status(h);
+}
+
+int mpopis_get_trajectories(mpopis_handle* h, double* out) {
+    if (!h || !out) return MPOPIS_ERR_ARG;
+    if (!h->d_traj) { h->err = "log_trajectories was not enabled"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_traj, sizeof(double) * h->B * h->K * h->T * h->ss, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+
+int mpopis_policy_step(mpopis_handle* h, const mpopis_noise* noise, double* control, double* cost, double* weights,
+                       double* E_out, int32_t* resample_idx0, int32_t* iters_run) {
+    if (!h) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, K = h->K, cs = h->cs, N = h->N;
+    const size_t per = (size_t)cs * K;
+    if (noise && noise->Z) {
+        if (!h->d_Zin) { if (dalloc(h, &h->d_Zin, (size_t)B * N * per)) return MPOPIS_ERR_HIP; }
+        HIPCHK(h, hipMemcpyAsync(h->d_Zin, noise->Z, sizeof(double) * B * N * per, hipMemcpyHostToDevice, h->stream));
+        if (h->cfg.policy == MPOPIS_POL_PMCMPPI && N > 1) {
+            if (!noise->res_i0 || !noise->res_u) { h->err = "pmcmppi with injected noise needs resampling draws"; return MPOPIS_ERR_ARG; }
+            if (!h->d_resi_in) { if (dalloc(h, &h->d_resi_in, (size_t)B * (N - 1) * K) || dalloc(h, &h->d_resu_in, (size_t)B * (N - 1) * K)) return MPOPIS_ERR_HIP; }
+            HIPCHK(h, hipMemcpyAsync(h->d_resi_in, noise->res_i0, sizeof(int32_t) * B * (N - 1) * K, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->d_resu_in, noise->res_u, sizeof(double) * B * (N - 1) * K, hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    int rc = h->policy_step_enqueue(noise && noise->Z);
+    if (rc) return rc;
+    if (control) HIPCHK(h, hipMemcpyAsync(control, h->d_control, sizeof(double) * B * h->as, hipMemcpyDeviceToHost, h->stream));
+    if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
+    if (weights) HIPCHK(h, hipMemcpyAsync(weights, h->d_w, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
+    if (E_out) {
+        // E .+= (pol.U - U_orig), returned in the reference layout.  d_Z is free at this point.
+        if (h->cfg.policy == MPOPIS_POL_MPPI) {
+            // reference E[k,t] (as-vectors, k fastest): element ((t*K+k)*as+a)  <- rows r=t*as+a
+            launch_mppi_E_out(h->d_E, h->d_Z, B, h->T, K, h->as, h->stream);
+        } else {
+            launch_transpose_out(h->d_E, h->d_Ucur, h->d_Uin, h->d_Z, B, cs, K, h->stream);
+        }
+        HIPCHK(h, hipMemcpyAsync(E_out, h->d_Z, sizeof(double) * B * per, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (resample_idx0 && N > 1) HIPCHK(h, hipMemcpyAsync(resample_idx0, h->d_residx_log, sizeof(int32_t) * B * (N - 1) * K, hipMemcpyDeviceToHost, h->stream));
+    if (iters_run) HIPCHK(h, hipMemcpyAsync(iters_run, h->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    rc = sync_status(h);
+    HIPCHK(h, hipGetLastError());
+    return rc;
+}
+
+int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double* records, double* actions) {
+    if (!h || !records) return MPOPIS_ERR_ARG;
+    return h->run_trials(num_steps, laps, records, actions);
+}
+
+int mpopis_timing_enable(mpopis_handle* h, int32_t on) {
+    if (!h) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (on && h->events.empty()) {
+        h->events.resize(2 * 8192);
+        for (auto& e : h->events) HIPCHK(h, hipEventCreate(&e));
+    }
+    h->timing = on != 0;
+    return MPOPIS_OK;
+}
+int mpopis_timing_reset(mpopis_handle* h) { if (!h) return MPOPIS_ERR_ARG; h->ev_used = 0; h->ev_slot.clear(); return MPOPIS_OK; }
+int mpopis_timing_read(mpopis_handle* h, char* names, int32_t names_cap, double* ms_total, int64_t* launches, int32_t* n) {
+    if (!h || !n) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    static const char* kNames[] = {"rollout", "sample", "potrf", "reweight", "moments", "select", "other"};
+    const int nslots = 7;
+    std::vector<double> ms(nslots, 0.0); std::vector<int64_t> cnt(nslots, 0);
+    for (size_t i = 0; i < h->ev_slot.size(); ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, h->events[2 * i], h->events[2 * i + 1]) == hipSuccess) { ms[h->ev_slot[i]] += t; cnt[h->ev_slot[i]]++; }
+    }
+    std::string nm;
+    const int m = std::min<int>(*n, nslots);
+    for (int i = 0; i < m; ++i) { if (i) nm += ";"; nm += kNames[i]; if (ms_total) ms_total[i] = ms[i]; if (launches) launches[i] = cnt[i]; }
+    if (names && names_cap > 0) { strncpy(names, nm.c_str(), names_cap - 1); names[names_cap - 1] = 0; }
+    *n = m;
+    return MPOPIS_OK;
+}
+
+int mpopis_bench_policy_steps(mpopis_handle* h, int32_t steps, double* ms, double* rollouts) {
+    if (!h || steps < 0) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    double rl = 0.0;
+    for (int s = 0; s < steps; ++s) {
+        int rc = h->policy_step_enqueue(false);
+        if (rc) return rc;
+        rl += (double)h->B * h->N * h->K;     // upper bound; CE/CMA early breaks are reported via iters
+    }
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t;
+    if (rollouts) *rollouts = rl;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int rc = sync_status(h);
+    HIPCHK(h, hipGetLastError());
+    return rc;
+}
+
+}  // extern "C"
+
+// ---- launch sequences -----------------------------------------------------------------------------
+void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act) {
+    RolloutArgs a;
+    a.env = env; a.B = B; a.K = K; a.T = T; a.cs = cs;
+    a.x0 = d_x; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
+    a.cost = d_cost; a.traj = d_traj; a.active = act;
+    time_begin(0);
+    launch_rollout(a, stream);
+    time_end();
+}
+
+// calculate_trajectory_costs(pol, env) for the configured policy + functor tail.  `injected`: noise
+// staged in d_Zin / d_resi_in / d_resu_in, else device Philox streams (mpc_step, iteration).
+int mpopis_handle::policy_step_enqueue(bool injected) {
+    const int pol = cfg.policy;
+    const size_t nn = (size_t)cs * cs, per = (size_t)cs * K;
+    const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
+    fill_i32(d_status, 0, B, stream);
+    fill_i32(d_active, 1, B, stream);
+    fill_i32(d_iters, 0, B, stream);
+    // U_orig = pol.U  (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop)
+    copy_f64(d_U, d_Uin, (size_t)B * cs, stream);
+    copy_f64(d_U, d_Ucur, (size_t)B * cs, stream);
+    if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
+    if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
+    for (int n = 1; n <= N; ++n) {
+        // ---- P = MvNormal(Σ′): Cholesky; Σ_inv only through gvec --------------------------------
+        const double* Lp; size_t Lstride; const double* dsc = nullptr;
+        const bool first_diag = sigma_diag && (sigma_fixed || n == 1);
+        if (sigma_fixed || (n == 1 && pol != MPOPIS_POL_CMAMPPI)) { Lp = d_L0; Lstride = 0; }
+        else {
+            time_begin(2);
+            launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream);
+            time_end();
+            Lp = d_L; Lstride = nn;
+        }
+        if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream);
+        // ---- E = rand(rng, P, K) ----------------------------------------------------------------
+        time_begin(1);
+        if (first_diag && !(pol == MPOPIS_POL_CMAMPPI)) {
+            hipLaunchKernelGGL(k_bcast_f64, dim3((cs + 255) / 256), dim3(256), 0, stream, d_dscale0, d_dscale, (size_t)cs, B);
+            dsc = d_dscale;
+        }
+        double* Zdst = dsc ? d_E : d_Z;
+        if (injected) {
+            // B x N x (cs x K col-major) -> rows; slot stride N*per
+            for (int b = 0; b < B; ++b) {
+                if (pol == MPOPIS_POL_MPPI) launch_mppi_Z_in(d_Zin + ((size_t)b * N + (n - 1)) * per, Zdst + (size_t)b * per, 1, T, K, as, stream);
+                else launch_transpose_in(d_Zin + ((size_t)b * N + (n - 1)) * per, Zdst + (size_t)b * per, 1, cs, K, stream);
+            }
+            if (dsc) launch_scale_rows(Zdst, dsc, B, cs, K, stream);
+        } else {
+            launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
+        }
+        if (!dsc) launch_trmm_LZ(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
+        time_end();
+        // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
+        rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active);
+        hipLaunchKernelGGL(k_set_iters, dim3((B + 255) / 256), dim3(256), 0, stream, d_iters, n, d_active, B);
+        // ---- adapt (μ, Σ′) ----------------------------------------------------------------------
+        if (n < N) {
+            int rc = ais_update(n, injected);
+            if (rc) return rc;
+        }
+    }
+    // weights = compute_weights(IT(λ), cost); weighted_noise = Σ_k w_k (E_k + (pol.U - U_orig)); roll
+    time_begin(3);
+    launch_weights(d_cost, d_w, B, K, cfg.lambda, nullptr, d_status, stream);
+    launch_wmean(d_E, d_w, d_Ucur, d_Uin, d_wn, B, cs, K, 0, nullptr, stream);
+    launch_finalize_env(d_wn, d_U, d_control, B, cs, as, T, env, stream);
+    time_end();
+    mpc_step += 1;
+    return MPOPIS_OK;
+}

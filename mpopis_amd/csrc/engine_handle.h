@@ -1,0 +1,56 @@
+// engine_handle.h -- the opaque handle behind include/mpopis.h (see engine.h for the HBM layout).
+#pragma once
+#include "engine.h"
+
+struct mpopis_handle {
+    mpopis_config cfg{};
+    int B = 0, K = 0, T = 0, as = 0, ss = 0, cs = 0, N = 1;
+    double gamma = 0.0;
+    hipStream_t stream = nullptr;
+    mpopis::EnvDesc env{};
+    std::string err;
+    std::vector<void*> allocs;
+    // resident env + policy state
+    double *d_x = nullptr, *d_U = nullptr, *d_Ucur = nullptr, *d_Uin = nullptr;
+    int *d_t = nullptr, *d_done = nullptr;
+    // proposal
+    double *d_Sigma0 = nullptr, *d_L0 = nullptr, *d_dscale0 = nullptr;   // shared pol.Σ, its factor, sqrt(diag)
+    double *d_Sig = nullptr, *d_L = nullptr, *d_tmpS = nullptr, *d_dscale = nullptr;
+    bool sigma_diag = false;
+    // samples / costs / weights
+    double *d_Z = nullptr, *d_E = nullptr, *d_Zin = nullptr, *d_cost = nullptr, *d_w = nullptr;
+    double *d_wn = nullptr, *d_mu = nullptr, *d_gvec = nullptr, *d_control = nullptr, *d_reward = nullptr, *d_traj = nullptr;
+    int *d_status = nullptr, *d_active = nullptr, *d_iters = nullptr;
+    uint64_t* d_seeds = nullptr;
+    // elite selection / resampling
+    int32_t *d_order = nullptr, *d_resi = nullptr, *d_alias = nullptr, *d_residx_log = nullptr, *d_resi_in = nullptr;
+    double *d_resu = nullptr, *d_accept = nullptr, *d_resu_in = nullptr;
+    // moments workspace
+    double* d_part = nullptr; int ksplit = 1;
+    // CMA (src/mppi_mpopi_policies.jl:513-525 constants; :536-545 per-call state)
+    int m_elite = 0;
+    double mu_eff = 0, c_sigma = 0, d_sigma = 0, c_Sigma = 0, c1 = 0, c_mu = 0, E_cma = 0;
+    double *d_cma = nullptr, *d_cma_ws = nullptr, *d_C = nullptr, *d_Y = nullptr, *d_Tm = nullptr;
+    // bookkeeping
+    uint64_t mpc_step = 0;
+    std::vector<int> h_status;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> events; std::vector<int> ev_slot; int ev_used = 0;
+
+    void time_begin(int slot);
+    void time_end();
+    void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act);
+    int policy_step_enqueue(bool injected);
+    int ais_update(int n, bool injected);
+    int run_trials(int num_steps, int laps, double* records, double* actions);
+    void init_cma_constants();
+    void cma_begin();
+    const double* cma_sigma2();
+};
+
+namespace mpopis {
+void launch_scale_rows(double* Z, const double* dsc, int B, int cs, int K, hipStream_t s);
+inline void launch_mppi_Z_in(const double* src, double* dst, int B, int T, int K, int as, hipStream_t s) { launch_transpose_in(src, dst, B * T, as, K, s); }
+inline void launch_mppi_E_out(const double* src, double* dst, int B, int T, int K, int as, hipStream_t s) { launch_transpose_out(src, nullptr, nullptr, dst, B * T, as, K, s); }
+}

@@ -1,0 +1,196 @@
+// kernels_reweight.hip -- softmax re-weighting and the weighted control update:
+//   compute_weights(::Information_Theoretic, costs)       src/utils.jl:79-86
+//   weighted_noise[r] = weights' * E[r, :]                src/mppi_mpopi_policies.jl:226-229 (:131-136 for :mppi)
+//   StatsBase mean(E, pw, dims=2) of the AIS mean update  :364,:662,:732
+//   get_controls_roll_U!                                  src/utils.jl:88-101
+//   E .+= (pol.U - U_orig)                                :370,:468,:602,:668,:739,:814 (folded into consumers)
+// plus the layout converters of the C ABI and the real-env step.
+// All of these are HBM/L2-bound reductions over k: wave64 shuffles + one LDS hop per workgroup.
+#include "engine.h"
+
+namespace mpopis {
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// all threads get the result; sh must hold >= blockDim/64 doubles; safe to call repeatedly
+template <bool IS_MIN>
+__device__ __forceinline__ double block_reduce(double v, double* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = IS_MIN ? wave_min(v) : wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = (lane < nw) ? sh[lane] : (IS_MIN ? INFINITY : 0.0);
+    r = IS_MIN ? wave_min(r) : wave_sum(r);
+    return r;
+}
+
+__global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cost, double* __restrict__ w, int K,
+                                                  double neg_inv_lambda, const int* active, int* status) {
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    __shared__ double sh[16];
+    const double* c = cost + (size_t)b * K;
+    double* wo = w + (size_t)b * K;
+    double m = INFINITY;
+    bool bad = false;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { const double v = c[k]; m = fmin(m, v); bad |= !(fabs(v) < INFINITY); }
+    m = block_reduce<true>(m, sh);                                             // ρ = minimum(costs)
+    double s = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const double e = exp(neg_inv_lambda * (c[k] - m));                     // exp(-1/λ * (c - ρ))
+        wo[k] = e; s += e;
+    }
+    s = block_reduce<false>(s, sh);                                            // η
+    for (int k = threadIdx.x; k < K; k += blockDim.x) wo[k] = wo[k] / s;
+    if (bad && status) atomicMin(&status[b], MPOPIS_ERR_ACTION);               // non-finite cost <=> NaN action (car_racing.jl:239)
+}
+
+void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(k_weights, dim3(B), dim3(K >= 1024 ? 1024 : 256), 0, s, cost, w, K, -1 / lambda, active, status);
+}
+
+__global__ void __launch_bounds__(256) k_wmean(const double* __restrict__ E, const double* __restrict__ w,
+                                               const double* shiftA, const double* shiftB, double* __restrict__ out,
+                                               int cs, int K, int normalize, const int* active) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    if (active && !active[b]) return;
+    __shared__ double sh[4];
+    const double* e = E + ((size_t)b * cs + r) * K;
+    const double* wb = w + (size_t)b * K;
+    const double sft = shiftA ? (shiftA[(size_t)b * cs + r] - shiftB[(size_t)b * cs + r]) : 0.0;
+    double acc = 0.0, ws = 0.0;
+    if ((K & 1) == 0) {                                                        // 16 B per lane
+        const double2* e2 = reinterpret_cast<const double2*>(e);
+        const double2* w2 = reinterpret_cast<const double2*>(wb);
+        for (int k = threadIdx.x; k < K / 2; k += 256) {
+            const double2 ev = e2[k], wv = w2[k];
+            acc = fma(wv.x, ev.x + sft, acc); acc = fma(wv.y, ev.y + sft, acc);
+            ws += wv.x + wv.y;
+        }
+    } else {
+        for (int k = threadIdx.x; k < K; k += 256) { acc = fma(wb[k], e[k] + sft, acc); ws += wb[k]; }
+    }
+    acc = block_reduce<false>(acc, sh);
+    if (normalize) { ws = block_reduce<false>(ws, sh); acc = acc / ws; }
+    if (threadIdx.x == 0) out[(size_t)b * cs + r] = acc;
+}
+
+void launch_wmean(const double* E, const double* w, const double* shiftA, const double* shiftB, double* out,
+                  int B, int cs, int K, int normalize, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_wmean, dim3(cs, B), dim3(256), 0, s, E, w, shiftA, shiftB, out, cs, K, normalize, active);
+}
+
+// weighted_controls = pol.U + weighted_noise; control = clamp(wc[1:as]); roll (alias quirk: the last
+// `as` entries of U never change)
+__global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ wn, double* U, double* control,
+                                                  int cs, int as, int T, EnvDesc env) {
+    extern __shared__ __attribute__((aligned(16))) double wc[];
+    const int b = blockIdx.x;
+    double* Ub = U + (size_t)b * cs;
+    for (int r = threadIdx.x; r < cs; r += blockDim.x) wc[r] = Ub[r] + wn[(size_t)b * cs + r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < as; i += blockDim.x) control[(size_t)b * as + i] = clampd(wc[i], env.lo[i], env.hi[i]);
+    if (T > 1) { for (int r = threadIdx.x; r < cs - as; r += blockDim.x) Ub[r] = wc[r + as]; }
+    else       { for (int r = threadIdx.x; r < cs; r += blockDim.x) Ub[r] = wc[r]; }
+}
+
+void launch_finalize_env(const double* wn, double* U, double* control, int B, int cs, int as, int T,
+                         const EnvDesc& env, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(B), dim3(256), cs * sizeof(double), s, wn, U, control, cs, as, T, env);
+}
+
+// cs x K column-major (ABI / Julia)  <->  [cs][K] rows (engine)
+__global__ void __launch_bounds__(256) k_transpose_in(const double* __restrict__ src, double* __restrict__ dst, int cs, int K) {
+    __shared__ double tile[32][33];
+    const int b = blockIdx.z;
+    const double* s = src + (size_t)b * cs * K;
+    double* d = dst + (size_t)b * cs * K;
+    const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                    // 32 x 8
+    for (int j = ty; j < 32; j += 8) { const int k = k0 + j, r = r0 + tx; if (k < K && r < cs) tile[j][tx] = s[(size_t)k * cs + r]; }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) { const int r = r0 + j, k = k0 + tx; if (k < K && r < cs) d[(size_t)r * K + k] = tile[tx][j]; }
+}
+__global__ void __launch_bounds__(256) k_transpose_out(const double* __restrict__ src, const double* shiftA, const double* shiftB,
+                                                       double* __restrict__ dst, int cs, int K) {
+    __shared__ double tile[32][33];
+    const int b = blockIdx.z;
+    const double* s = src + (size_t)b * cs * K;
+    double* d = dst + (size_t)b * cs * K;
+    const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, k = k0 + tx;
+        if (k < K && r < cs) tile[j][tx] = s[(size_t)r * K + k] + (shiftA ? (shiftA[(size_t)b * cs + r] - shiftB[(size_t)b * cs + r]) : 0.0);
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) { const int k = k0 + j, r = r0 + tx; if (k < K && r < cs) d[(size_t)k * cs + r] = tile[tx][j]; }
+}
+void launch_transpose_in(const double* src, double* dst, int B, int cs, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_in, dim3((cs + 31) / 32, (K + 31) / 32, B), dim3(256), 0, s, src, dst, cs, K);
+}
+void launch_transpose_out(const double* src, const double* shiftA, const double* shiftB, double* dst, int B, int cs, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_transpose_out, dim3((cs + 31) / 32, (K + 31) / 32, B), dim3(256), 0, s, src, shiftA, shiftB, dst, cs, K);
+}
+
+// env(action); reward(env) for the resident real envs (one workgroup per slot, lane c = car c)
+__global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t, int* done, const double* action,
+                                                 double* reward, int* status) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    __shared__ double srew[kMaxCars];
+    if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
+        if (c == 0) {
+            const double a = action[b];
+            if (!(a >= env.lo[0] && a <= env.hi[0])) { if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION); }
+            int tt = t[b], dd = done[b];
+            mc_step(env.mc, x + (size_t)b * 2, &tt, &dd, a);
+            t[b] = tt; done[b] = dd;
+            if (reward) reward[b] = mc_reward(env.mc, x + (size_t)b * 2, dd);
+        }
+        return;
+    }
+    const int NC = env.ncars;
+    double* xb = x + (size_t)b * 8 * NC;
+    if (c < NC) {
+        const double a0 = action[(size_t)b * 2 * NC + 2 * c], a1 = action[(size_t)b * 2 * NC + 2 * c + 1];
+        if (NC == 1 && !(a0 >= env.lo[0] && a0 <= env.hi[0] && a1 >= env.lo[1] && a1 <= env.hi[1])) {
+            if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION);                // car_racing.jl:239
+        }
+        double s[8];
+        for (int i = 0; i < 8; ++i) s[i] = xb[8 * c + i];
+        car_action_step(env.car, s, a0, a1);
+        for (int i = 0; i < 8; ++i) xb[8 * c + i] = s[i];
+        srew[c] = car_reward(env.car, env.track, s);
+    }
+    __syncthreads();
+    if (c == 0) {
+        t[b] += 1;
+        if (reward) {
+            double rew = 0.0;
+            for (int i = 0; i < NC; ++i) {
+                rew += srew[i];
+                for (int j = i + 1; j < NC; ++j) {
+                    const double dx = xb[8 * j] - xb[8 * i], dy = xb[8 * j + 1] - xb[8 * i + 1];
+                    const double dd = sqrt(dx * dx + dy * dy);
+                    rew += -dd;
+                    if (dd <= 4.0) rew += -11000.0;
+                }
+            }
+            reward[b] = rew;
+        }
+    }
+}
+void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action, double* reward, int* status, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_step, dim3(B), dim3(64), 0, s, env, x, t, done, action, reward, status);
+}
+
+}  // namespace mpopis

@@ -1,0 +1,135 @@
+// kernels_rollout.hip -- the fused model-rollout kernel: replaces, per sample k,
+//   simulate_model            src/mppi_mpopi_policies.jl:261-278  (V = pol.U + E[:,k], control cost, clamp)
+//   calculate_trajectory_costs(::MPPI_Policy) inner loop  :198-214
+//   get_model_controls        src/utils.jl:55-67
+//   rollout_model             src/utils.jl:129-144
+//   env(a) + reward(env)      car_racing.jl:238-344,201-213; multi-car_racing.jl:200-207,145-158;
+//                             mountaincar_example.jl:4-22
+// in ONE launch, state in registers, no per-sample env copies (the reference deep-copies the env
+// per sample, :270).
+//
+// Mapping (CDNA4): lane = sample k, wave = car.  A workgroup is 64 samples x NC cars (NC waves); the
+// cars of one sample exchange (x,y) through LDS once per model step for the pairwise terms of the
+// multi-car reward.  E is [cs][K] (K fastest) so each per-step control load is one coalesced
+// 512-B transaction per wave; the nominal control U, the env state and the 48-point track are
+// wave-uniform and arrive through the scalar cache.  The kernel is FP64-VALU bound;
+// HBM traffic is 8*cs bytes per sample.
+#include "engine.h"
+
+namespace mpopis {
+
+template <int NC>
+__global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
+    const int b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    const int lane = threadIdx.x & 63;
+    const int c = (NC > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int k = blockIdx.x * 64 + lane;
+    const int K = a.K, T = a.T;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    constexpr int as = 2 * NC, ss = 8 * NC;
+
+    const CarParams& p = a.env.car;
+    const Track tk = a.env.track;
+    double s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = a.x0[b * ss + 8 * c + i];
+    const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
+    const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
+    const double* Uo = a.Uorig + (size_t)b * a.cs + 2 * c;
+    const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs + 2 * c : nullptr;
+    const double lo0 = a.env.lo[2 * c], hi0 = a.env.hi[2 * c], lo1 = a.env.lo[2 * c + 1], hi1 = a.env.hi[2 * c + 1];
+    double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
+
+    __shared__ double sh_xy[2][NC][2][64];
+    __shared__ double sh_cost[NC][64];
+
+    double cost = 0.0, cc = 0.0;
+    double e0 = Eb[0], e1 = Eb[K];
+    for (int t = 0; t < T; ++t) {
+        const double v0 = Ub[t * as] + e0, v1 = Ub[t * as + 1] + e1;           // V = pol.U + E[:,k]  :271
+        if (t + 1 < T) { e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K]; }
+        if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
+        const double a0 = clampd(v0, lo0, hi0), a1 = clampd(v1, lo1, hi1);     // get_model_controls
+        car_action_step(p, s, a0, a1);
+        double rew = car_reward(p, tk, s);
+        if (NC > 1) {                                                          // multi-car_racing.jl:145-158
+            const int buf = t & 1;
+            sh_xy[buf][c][0][lane] = s[0];
+            sh_xy[buf][c][1][lane] = s[1];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                if (j > c) {
+                    const double dx = sh_xy[buf][j][0][lane] - s[0], dy = sh_xy[buf][j][1][lane] - s[1];
+                    const double dd = sqrt(dx * dx + dy * dy);
+                    rew += -dd;
+                    if (dd <= 4.0) rew += -11000.0;
+                }
+            }
+        }
+        cost -= rew;                                                           // utils.jl:138
+        if (tr && valid) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tr[(size_t)(8 * c + i) * T + t] = s[i];   // trajectories[k][t, :] utils.jl:140
+        }
+    }
+    cost += cc;
+    if (NC > 1) {
+        sh_cost[c][lane] = cost;
+        __syncthreads();
+        if (c == 0) {
+            double tot = cost;
+#pragma unroll
+            for (int j = 1; j < NC; ++j) tot += sh_cost[j][lane];
+            if (valid) a.cost[(size_t)b * K + k] = tot;
+        }
+    } else {
+        if (valid) a.cost[(size_t)b * K + k] = cost;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_rollout_mountaincar(RolloutArgs a) {
+    const int b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int K = a.K, T = a.T;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    const McParams& p = a.env.mc;
+    double s[2] = { a.x0[b * 2], a.x0[b * 2 + 1] };
+    int t_env = a.t0 ? a.t0[b] : 0, done = a.done0 ? a.done0[b] : 0;
+    const double* Eb = a.E + (size_t)b * a.cs * K + kk;
+    const double* Ub = a.Ucur + (size_t)b * a.cs;
+    const double* Uo = a.Uorig + (size_t)b * a.cs;
+    const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs : nullptr;
+    double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(2 * T) : nullptr;
+    double cost = 0.0, cc = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double v = Ub[t] + Eb[(size_t)t * K];
+        if (gv) cc += gv[t] * (v - Uo[t]);
+        const double act = clampd(v, a.env.lo[0], a.env.hi[0]);
+        mc_step(p, s, &t_env, &done, act);
+        cost -= mc_reward(p, s, done);
+        if (tr && valid) { tr[t] = s[0]; tr[T + t] = s[1]; }
+    }
+    if (valid) a.cost[(size_t)b * K + k] = cost + cc;
+}
+
+void launch_rollout(const RolloutArgs& a, hipStream_t st) {
+    dim3 grid((a.K + 63) / 64, a.B);
+    if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
+        hipLaunchKernelGGL(k_rollout_mountaincar, grid, dim3(64), 0, st, a);
+        return;
+    }
+    switch (a.env.ncars) {
+        case 1: hipLaunchKernelGGL(k_rollout_car<1>, grid, dim3(64), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(k_rollout_car<2>, grid, dim3(128), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(k_rollout_car<3>, grid, dim3(192), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(k_rollout_car<4>, grid, dim3(256), 0, st, a); break;
+        default: break;
+    }
+}
+
+}  // namespace mpopis

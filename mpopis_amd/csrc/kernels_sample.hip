@@ -1,0 +1,122 @@
+// kernels_sample.hip -- proposal sampling on device:
+//   randn!(rng, cs x K)  +  unwhiten!: E = L*Z   (Distributions.rand(rng, MvNormal(Σ), K) as called at
+//   src/mppi_mpopi_policies.jl:308,359,448,556,657,724,797; rand(rng,P,K,T) at :193 for :mppi)
+// The reference stream (Julia MersenneTwister + ziggurat) is not reproduced; the engine draws from
+// Philox4x32-10 counter streams + Box-Muller (bit-identical to the oracle's generator up to the
+// last-ulp differences of log/sin/cos) or consumes injected normals.  Counter = normal-pair index
+// of the reference's linear draw order; key = per-trial seed; stream = (mpc step, AIS iteration).
+#include "engine.h"
+
+namespace mpopis {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, double* z0, double* z1) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
+    const double two_m53 = 1.0 / 9007199254740992.0;
+    const double u1 = ((double)(a >> 11) + 0.5) * two_m53;
+    const double u2 = ((double)(b >> 11) + 0.5) * two_m53;
+    const double R = sqrt(-2.0 * log(u1));
+    double s, c;
+    sincos(kTwoPi * u2, &s, &c);
+    *z0 = R * c; *z1 = R * s;
+}
+
+// Z[b][r][k] (K fastest) = standard normal number `lin` of the reference's draw order, scaled by
+// dscale[r] when the Cholesky factor is diagonal (then Z is already E).
+//   G-variants: lin = k*cs + r            (randn! fills the cs x K matrix column-major)
+//   :mppi     : lin = (t*K + k)*as + a    with r = t*as + a  (k fastest, then t)
+__global__ void __launch_bounds__(256) k_sample_normal(double* __restrict__ Z, int cs, int K, int as, int mppi_order,
+                                                       const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                                                       const double* dscale, const int* active) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (k >= K) return;
+    uint64_t lin;
+    if (mppi_order) { const int t = r / as, a = r - t * as; lin = ((uint64_t)t * K + k) * as + a; }
+    else lin = (uint64_t)k * cs + r;
+    double z0, z1;
+    philox_normal_pair(seeds[b], slo, shi, lin >> 1, &z0, &z1);
+    double z = (lin & 1) ? z1 : z0;
+    if (dscale) z *= dscale[(size_t)b * cs + r];
+    Z[((size_t)b * cs + r) * K + k] = z;
+}
+
+void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
+                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
+}
+
+// resampling draws for :pmcmppi (rand(rng, Categorical(ws), K), :805): i uniform in [0,K), u in [0,1)
+__global__ void __launch_bounds__(256) k_sample_resample_draws(int32_t* di, double* du, int K, const uint64_t* seeds,
+                                                               uint32_t slo, uint32_t shi, const int* active) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    uint32_t r[4];
+    const uint64_t seed = seeds[b];
+    philox4x32_10((uint32_t)k, 0u, slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const uint64_t a = ((uint64_t)r[1] << 32) | r[0], bb = ((uint64_t)r[3] << 32) | r[2];
+    const double two_m53 = 1.0 / 9007199254740992.0;
+    int i = (int)((double)(a >> 11) * two_m53 * K);
+    if (i >= K) i = K - 1;
+    di[(size_t)b * K + k] = i;
+    du[(size_t)b * K + k] = (double)(bb >> 11) * two_m53;
+}
+void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                                  const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample_resample_draws, dim3((K + 255) / 256, B), dim3(256), 0, s, di, du, K, seeds, slo, shi, active);
+}
+
+// E = L*Z, L lower-triangular n x n column-major per slot (Lstride = n*n, or 0 when shared),
+// Z,E [n][K].  First-cut FP64 VALU kernel: 16 rows x 256 samples per workgroup, L through the scalar
+// cache.  In-place is NOT allowed (E != Z).
+constexpr int kTrmmRows = 16;
+__global__ void __launch_bounds__(256) k_trmm_LZ(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
+                                                 double* __restrict__ E, int n, int K, const int* active) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * kTrmmRows;
+    const double* Lb = L + (size_t)b * Lstride;
+    const double* Zb = Z + (size_t)b * n * K;
+    double acc[kTrmmRows];
+#pragma unroll
+    for (int ii = 0; ii < kTrmmRows; ++ii) acc[ii] = 0.0;
+    const int kk = k < K ? k : K - 1;
+    const int jmax = min(n, i0 + kTrmmRows);
+    for (int j = 0; j < jmax; ++j) {
+        const double z = Zb[(size_t)j * K + kk];
+#pragma unroll
+        for (int ii = 0; ii < kTrmmRows; ++ii) {
+            const int i = i0 + ii;
+            const double l = (i < n && j <= i) ? Lb[(size_t)i + (size_t)j * n] : 0.0;
+            acc[ii] = fma(l, z, acc[ii]);
+        }
+    }
+    if (k < K) {
+#pragma unroll
+        for (int ii = 0; ii < kTrmmRows; ++ii) if (i0 + ii < n) E[((size_t)b * n + i0 + ii) * K + k] = acc[ii];
+    }
+}
+void launch_trmm_LZ(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_trmm_LZ, dim3((K + 255) / 256, (n + kTrmmRows - 1) / kTrmmRows, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active);
+}
+
+}  // namespace mpopis

@@ -1,0 +1,27 @@
+// Test-only host build of the engine's shared dynamics header (mpopis_amd/csrc/car_dynamics.h), so
+// the fast-path algebra used by the HIP rollout kernel can be checked against the CPU oracle on a
+// machine without a GPU.  Not part of the product; never loaded by mpopis_amd.
+#include "../../mpopis_amd/csrc/car_dynamics.h"
+using namespace mpopis;
+extern "C" {
+void shim_car_action_step(const double* p20, double* s8, double a0, double a1) {
+    CarParams p = make_car_params(p20);
+    car_action_step(p, s8, a0, a1);
+}
+double shim_car_reward(const double* p20, int P, const double* tx, const double* ty, const double* tw, const double* s8) {
+    CarParams p = make_car_params(p20);
+    Track tk{tx, ty, tw, P};
+    return car_reward(p, tk, s8);
+}
+// full single-car rollout: controls as x T (already clamped); returns -sum(reward)
+double shim_car_rollout(const double* p20, int P, const double* tx, const double* ty, const double* tw,
+                        double* s8, const double* ctrl, int T) {
+    CarParams p = make_car_params(p20);
+    Track tk{tx, ty, tw, P};
+    double c = 0.0;
+    for (int t = 0; t < T; ++t) { car_action_step(p, s8, ctrl[2 * t], ctrl[2 * t + 1]); c -= car_reward(p, tk, s8); }
+    return c;
+}
+void shim_mc_step(const double* p8, double* s2, int* t, int* done, double f) { McParams p = make_mc_params(p8); mc_step(p, s2, t, done, f); }
+double shim_mc_reward(const double* p8, const double* s2, int done) { McParams p = make_mc_params(p8); return mc_reward(p, s2, done); }
+}
