@@ -12,14 +12,14 @@
 // VALU instructions of OCML code per sub-step and dominate the whole MPC step.  The fast path here
 // removes every transcendental from the sub-step with exact identities:
 //   * tan(atan2(y,x) - d) = (y cos d - x sin d)/(x cos d + y sin d); |a| < atan(T) <=> in-half-plane
-//     and |tan a| < T; so slip angles are never materialised (valid while Vx > 0; otherwise the
-//     literal slow path runs, see car_substep_literal).
+//     and |tan a| < T; so slip angles are never materialised (all signs of Vx handled, see
+//     car_action_step).
 //   * the pedal, hence fx, fz and the brush-model constants (fy_max, 3fy_max/C, C^2/3fy_max,
 //     C^3/27fy_max^2) are constant over the 10 sub-steps of one action -> hoisted (2 sqrt per
 //     action instead of per sub-step).
 //   * sin/cos of delta and psi advance by angle-addition with the per-sub-step increments
-//     (|d_delta| <= 0.0157, |d_psi| = |psi_dot|*0.01), re-synchronised from a true sincos at
-//     every action step; psi's atan(sin,cos) wrap is a conditional +-2pi.
+//     (|d_delta| <= 0.0157, |d_psi| = |psi_dot|*0.01), carried in the state and renormalised once per
+//     action; psi's atan(sin,cos) wrap is a conditional +-2pi; |β| > β_limit is a ratio test.
 // These agree with the literal formulas to rounding (~1e-15 relative per step); the parity
 // tests bound the end-to-end deviation against the CPU oracle at 1e-9 relative, far inside the
 // 1e-5 contract.
@@ -28,10 +28,8 @@
 
 #if defined(__HIPCC__)
 #define MP_HD __host__ __device__ __forceinline__
-#define MP_HD_NOINLINE inline __host__ __device__ __attribute__((noinline))
 #else
 #define MP_HD inline
-#define MP_HD_NOINLINE inline
 #endif
 
 namespace mpopis {
@@ -46,7 +44,8 @@ struct CarParams {
     double m, Izz, h, lf, lr, CD0, CD1, Caf, Car, muf, mur, dmax, ddotmax, Fxmax, Fxmin, lbrake, ldrive, blim, dt, ddt;
     // derived on the host once
     int nsub;            // round(Int, dt/δt) :299
-    double inv_m, inv_Izz, L;
+    int blim_acute;      // β_limit < pi/2
+    double inv_m, inv_Izz, L, tan_blim;
 };
 
 MP_HD CarParams make_car_params(const double* p) {
@@ -57,6 +56,8 @@ MP_HD CarParams make_car_params(const double* p) {
     c.dt = p[18]; c.ddt = p[19];
     c.nsub = (int)nearbyint(c.dt / c.ddt);
     c.inv_m = 1 / c.m; c.inv_Izz = 1 / c.Izz; c.L = c.lr + c.lf;
+    c.blim_acute = c.blim < 0.5 * kPi;
+    c.tan_blim = c.blim_acute ? tan(c.blim) : tan(kPi - c.blim);
     return c;
 }
 
@@ -100,114 +101,116 @@ MP_HD void sincos_small(double v, double* s, double* c) {
     *c = fma(-pc, v2, 1.0);
 }
 
-// ---- literal restatement of the reference sub-step; taken when Vx <= 0 (or NaN) ---------------
-// src/envs/car_racing.jl:252-260
-MP_HD double tire_fy_literal(double alpha, double mu, double Ca, double fzt, double fxt) {
-    double fy_max = sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));
-    double ta = tan(alpha);
-    if (fabs(alpha) < atan(3 * fy_max / Ca))
-        return -Ca * ta + ((Ca * Ca) / (3 * fy_max)) * fabs(ta) * ta - ((Ca * Ca * Ca) / (27 * (fy_max * fy_max))) * (ta * ta * ta);
-    return -fy_max * jl_sign(alpha);
-}
-
-// one Euler sub-step exactly as src/envs/car_racing.jl:301-332 (delta already advanced)
-MP_HD_NOINLINE void car_substep_literal(const CarParams& p, double rate_unused, double pedal, double delta,
-                                        double* x, double* y, double* psi, double* Vx_, double* Vy_, double* r_) {
-    (void)rate_unused;
-    double Vx = *Vx_, Vy = *Vy_, r = *r_;
-    double alpha_f = atan2(Vy + p.lf * r, Vx) - delta;
-    double alpha_r = atan2(Vy - p.lr * r, Vx);
-    double fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * jl_sign(Vx);
-    double accel = p.Fxmax * fmax(pedal, 0.0);
-    double brake = p.Fxmin * fmin(pedal, 0.0) * jl_sign(Vx);
-    double fx = accel + brake;
-    double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
-    double fxf = lam * fx, fxr = (1 - lam) * fx;
-    double fzf = (p.m * p.lr * 9.81 - p.h * fx) / p.L;
-    double fzr = (p.m * p.lf * 9.81 + p.h * fx) / p.L;
-    double fyf = tire_fy_literal(alpha_f, p.muf, p.Caf, fzf, fxf);
-    double fyr = tire_fy_literal(alpha_r, p.mur, p.Car, fzr, fxr);
-    double sd = sin(delta), cd = cos(delta);
-    double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);
-    double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;
-    double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;
-    r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;
-    double ps = *psi + r * p.ddt;
-    ps = atan2(sin(ps), cos(ps));
-    *x += (Vx * cos(ps) - Vy * sin(ps)) * p.ddt;
-    *y += (Vx * sin(ps) + Vy * cos(ps)) * p.ddt;
-    *psi = ps; *Vx_ = Vx; *Vy_ = Vy; *r_ = r;
-}
-
 struct TireK { double fymax, thr, k2, k3; };
 
 MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
     TireK k;
-    k.fymax = sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));
+    k.fymax = sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));           // :253
     k.thr = 3 * k.fymax / Ca;                                  // tan of the switch angle :255
     k.k2 = (Ca * Ca) / (3 * k.fymax);
     k.k3 = (Ca * Ca * Ca) / (27 * (k.fymax * k.fymax));
     return k;
 }
 
-// env(a) for one car: s = [x,y,psi,Vx,Vy,psi_dot,delta,pedal]; a0 steering, a1 pedal (already clamped)
-MP_HD void car_action_step(const CarParams& p, double* s, double a0, double a1) {
-    double x = s[0], y = s[1], psi = s[2], Vx = s[3], Vy = s[4], r = s[5], delta = s[6];
+// Car state as the kernels carry it: the reference's 8 doubles plus sin/cos of psi and delta, which
+// are advanced by angle addition and never re-evaluated inside a rollout.
+struct CarState { double x, y, psi, Vx, Vy, r, delta, pedal, sp, cp, sd, cd; };
+constexpr int kCarExt = 12;
+
+MP_HD void car_state_from8(CarState& c, const double* s) {     // the only place sin/cos are evaluated
+    c.x = s[0]; c.y = s[1]; c.psi = s[2]; c.Vx = s[3]; c.Vy = s[4]; c.r = s[5]; c.delta = s[6]; c.pedal = s[7];
+    c.sp = sin(c.psi); c.cp = cos(c.psi); c.sd = sin(c.delta); c.cd = cos(c.delta);
+}
+MP_HD void car_state_to8(const CarState& c, double* s) {
+    s[0] = c.x; s[1] = c.y; s[2] = c.psi; s[3] = c.Vx; s[4] = c.Vy; s[5] = c.r; s[6] = c.delta; s[7] = c.pedal;
+}
+
+// env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
+// Transcendental-free for every sign of Vx (requires |delta| < pi/2, guaranteed by delta_max and
+// actions in [-1,1]):
+//   rear : alpha_r = atan2(yr,Vx).  |alpha_r| < atan(T)  <=>  Vx > 0 and |yr/Vx| < T; tan(alpha_r) = yr/Vx;
+//          otherwise saturated with sign(alpha_r) = sign(yr) (atan2(0,0) = 0 gives fy = 0).
+//   front: alpha_f = atan2(yf,Vx) - delta is the angle of q = R(-delta)(Vx,yf) up to a 2pi wrap that can
+//          only occur when |alpha_f| > pi (saturated anyway).  Linear branch <=> q.x > 0 and |q.y/q.x| < T;
+//          saturated sign = sign(q.y) if q.x > 0 else sign(yf) (|alpha_f| >= pi/2 > |delta|).
+MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1) {
+    double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r, delta = c.delta;
+    double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
+    {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation, error ~1e-32)
+        const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
+        sp *= fp; cp *= fp; sd *= fd; cd *= fd;
+    }
     const double tgt = a0 * p.dmax - delta;
     const double rate = fmin(fabs(tgt) / p.dt, p.ddotmax) * jl_sign(tgt);      // :295-296
     const double dd = rate * p.ddt;
     const double pedal = a1;                                                   // :297
-    // constant over the sub-steps while Vx > 0 (sign(Vx) = 1): :310-318
-    const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0);
-    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
-    const double fxf = lam * fx, fxr = (1 - lam) * fx;
-    const double fzf = (p.m * p.lr * 9.81 - p.h * fx) / p.L;
-    const double fzr = (p.m * p.lf * 9.81 + p.h * fx) / p.L;
-    const TireK kf = tire_consts(p.muf, p.Caf, fzf, fxf);
-    const TireK kr = tire_consts(p.mur, p.Car, fzr, fxr);
-    double sd, cd, sdd, cdd, sp, cp;
-    sincos(delta, &sd, &cd);
-    sincos_small(dd, &sdd, &cdd);                              // |dd| <= ddotmax*δt
-    sincos(psi, &sp, &cp);
+    const double accel = p.Fxmax * fmax(pedal, 0.0);                           // :310
+    const double brk = p.Fxmin * fmin(pedal, 0.0);                             // :311 without sign(Vx)
+    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;                     // :315-316
+    const double fz0f = p.m * p.lr * 9.81, fz0r = p.m * p.lf * 9.81;          // :262-272
+    // forces and brush-model constants are constant over the sub-steps while Vx > 0 -> hoisted
+    double fxf = lam * (accel + brk), fxr = (1 - lam) * (accel + brk);
+    TireK kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * (accel + brk)) / p.L, fxf);
+    TireK kr = tire_consts(p.mur, p.Car, (fz0r + p.h * (accel + brk)) / p.L, fxr);
+    bool hoisted_valid = true;
+    double sdd, cdd;
+    sincos_small(dd, &sdd, &cdd);                              // |dd| <= ddotmax*δt = 0.0157
     for (int it = 0; it < p.nsub; ++it) {
         delta += dd;                                                           // :301
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }
-        if (!(Vx > 0.0)) {                                     // rare: stopped / sliding backwards / NaN
-            car_substep_literal(p, rate, pedal, delta, &x, &y, &psi, &Vx, &Vy, &r);
-            sincos(psi, &sp, &cp);
-            continue;
+        double fx_aero;
+        if (Vx > 0.0) {
+            if (!hoisted_valid) {                              // came back from Vx <= 0
+                fxf = lam * (accel + brk); fxr = (1 - lam) * (accel + brk);
+                kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * (accel + brk)) / p.L, fxf);
+                kr = tire_consts(p.mur, p.Car, (fz0r + p.h * (accel + brk)) / p.L, fxr);
+                hoisted_valid = true;
+            }
+            fx_aero = fma(p.CD1, Vx, p.CD0);                                   // :308
+        } else {                                               // rare: stopped or sliding backwards
+            const double sg = jl_sign(Vx);
+            const double fx = accel + brk * sg;                                // :310-312
+            fxf = lam * fx; fxr = (1 - lam) * fx;
+            kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * fx) / p.L, fxf);
+            kr = tire_consts(p.mur, p.Car, (fz0r + p.h * fx) / p.L, fxr);
+            hoisted_valid = false;
+            fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;
         }
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
-        // rear: alpha_r = atan2(yr, Vx) in (-pi/2, pi/2)
+        // rear tyre
         const double tar = yr * fast_rcp(Vx);
-        const double fyr = (fabs(tar) < kr.thr)
-            ? (-p.Car * tar + kr.k2 * fabs(tar) * tar - kr.k3 * (tar * tar * tar))
-            : -kr.fymax * jl_sign(yr);
-        // front: alpha_f = atan2(yf, Vx) - delta = angle of (Vx, yf) rotated by -delta, |alpha_f| < pi
-        const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));
+        double fyr;
+        if (Vx > 0.0 && fabs(tar) < kr.thr) fyr = -p.Car * tar + kr.k2 * fabs(tar) * tar - kr.k3 * (tar * tar * tar);
+        else fyr = (Vx == 0.0 && yr == 0.0) ? 0.0 : ((yr >= 0.0) ? -kr.fymax : kr.fymax);
+        // front tyre
+        double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));
+        if (Vx == 0.0 && yf == 0.0) { xq = cd; yq = -sd; }     // atan2(0,0) = 0 -> alpha_f = -delta
         const double taf = yq * fast_rcp(xq);
-        const double fyf = (xq > 0.0 && fabs(taf) < kf.thr)
-            ? (-p.Caf * taf + kf.k2 * fabs(taf) * taf - kf.k3 * (taf * taf * taf))
-            : -kf.fymax * jl_sign(yq);
-        const double fx_aero = fma(p.CD1, Vx, p.CD0);                          // :308, Vx > 0
+        double fyf;
+        if (xq > 0.0 && fabs(taf) < kf.thr) fyf = -p.Caf * taf + kf.k2 * fabs(taf) * taf - kf.k3 * (taf * taf * taf);
+        else fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -kf.fymax : kf.fymax;
         const double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);          // :322
         const double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;                   // :323
         const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;         // :324
         r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;               // :326-328
-        const double dpsi = r * p.ddt;
+        double dpsi = r * p.ddt;
         psi += dpsi;                                                           // :329
-        if (fabs(dpsi) <= 0.25) {
-            double sq, cq; sincos_small(dpsi, &sq, &cq);
-            const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2;
-            if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;  // :330 atan(sin,cos)
-        } else {
-            psi = atan2(sin(psi), cos(psi));
-            sincos(psi, &sp, &cp);
+        if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;      // :330 atan(sin,cos)
+        int nrot = 1;
+        if (fabs(dpsi) > 0.25) {                               // absurd yaw rates (> 25 rad/s): split the rotation
+            nrot = (int)fmin(ceil(fabs(dpsi) * 4.0), 1024.0);
+            dpsi = dpsi / nrot;
+            psi = fmod(psi, kTwoPi);
+            if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;
         }
+        double sq, cq;
+        sincos_small(dpsi, &sq, &cq);
+        for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
         x += (Vx * cp - Vy * sp) * p.ddt;                                      // :331
         y += (Vx * sp + Vy * cp) * p.ddt;                                      // :332
     }
-    s[0] = x; s[1] = y; s[2] = psi; s[3] = Vx; s[4] = Vy; s[5] = r; s[6] = delta; s[7] = pedal;
+    c.x = x; c.y = y; c.psi = psi; c.Vx = Vx; c.Vy = Vy; c.r = r; c.delta = delta; c.pedal = pedal;
+    c.sp = sp; c.cp = cp; c.sd = sd; c.cd = cd;
 }
 
 // within_track(track, pos): car_racing_tracks.jl:68-92.  Track arrays are wave-uniform (scalar loads).
@@ -218,6 +221,7 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out)
         const double dx = tk.x[0] - px, dy = tk.y[0] - py;
         best = dx * dx + dy * dy;
     }
+#pragma unroll 4
     for (int i = 1; i < tk.P; ++i) {                                           // findmin: first minimum
         const double dx = tk.x[i] - px, dy = tk.y[i] - py;
         const double d = dx * dx + dy * dy;
@@ -239,14 +243,20 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out)
 }
 
 // reward(env::CarRacingEnv): src/envs/car_racing.jl:201-213
-MP_HD double car_reward(const CarParams& p, const Track& tk, const double* s) {
+// |atan2(Vy,Vx)| > β_limit without the atan2 (tan_blim = tan(β_limit) or tan(pi-β_limit), host-side)
+MP_HD bool exceed_beta(const CarParams& p, double Vx, double Vy) {
+    if (p.blim_acute) return (Vx > 0.0) ? (fabs(Vy) > p.tan_blim * Vx) : !(Vx == 0.0 && Vy == 0.0);
+    return (Vx < 0.0) && (fabs(Vy) < p.tan_blim * (-Vx));
+}
+
+MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y, double Vx, double Vy) {
     double dist;
-    const bool within = within_track(tk, s[0], s[1], &dist);
+    const bool within = within_track(tk, x, y, &dist);
     double rew = 0.0;
     if (!within) rew += -1000000.0;
-    if (fabs(atan2(s[4], s[3])) > p.blim) rew += -5000.0;                      // exceed_β :184-189
+    if (exceed_beta(p, Vx, Vy)) rew += -5000.0;                                // exceed_β :184-189
     rew += -dist;
-    rew += 2.0 * sqrt(s[3] * s[3] + s[4] * s[4]);
+    rew += 2.0 * sqrt(Vx * Vx + Vy * Vy);
     return rew;
 }
 

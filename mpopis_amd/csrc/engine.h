@@ -38,7 +38,8 @@ struct EnvDesc {
 struct RolloutArgs {
     EnvDesc env;
     int B, K, T, cs;
-    const double* x0;      // [B][ss]
+    const double* x0;      // [B][ss]   (MountainCar)
+    const double* x0ext;   // [B][ncars][12] car start states + sin/cos (launch_extend_state)
     const int* t0;         // [B] (MountainCar step counter) or nullptr
     const int* done0;      // [B]
     const double* Ucur;    // [B][cs]
@@ -51,6 +52,7 @@ struct RolloutArgs {
 };
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
+void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s);
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,

@@ -122,7 +122,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     const int B = h->B, K = h->K, cs = h->cs;
     const size_t nn = (size_t)cs * cs;
     int rc = 0;
-    rc |= dalloc(h, &h->d_x, (size_t)B * h->ss); rc |= dalloc(h, &h->d_t, B); rc |= dalloc(h, &h->d_done, B);
+    rc |= dalloc(h, &h->d_x, (size_t)B * h->ss); rc |= dalloc(h, &h->d_xext, (size_t)B * kMaxCars * kCarExt); rc |= dalloc(h, &h->d_t, B); rc |= dalloc(h, &h->d_done, B);
     rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
     rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
     rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
@@ -144,9 +144,10 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     h->h_status.assign(B, 0);
     // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
-    std::vector<double> eye(nn, 0.0);
-    for (int i = 0; i < cs; ++i) eye[(size_t)i * cs + i] = 1.0;
-    if (mpopis_set_Sigma(h, eye.data(), cs) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    const int n0 = (cfg->policy == MPOPIS_POL_MPPI) ? h->as : cs;
+    std::vector<double> eye((size_t)n0 * n0, 0.0);
+    for (int i = 0; i < n0; ++i) eye[(size_t)i * n0 + i] = 1.0;
+    if (mpopis_set_Sigma(h, eye.data(), n0) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     if (mpopis_seed(h, cfg->seed) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     if (mpopis_reset(h) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     if (cfg->policy == MPOPIS_POL_CMAMPPI) h->init_cma_constants();
@@ -178,7 +179,7 @@ int mpopis_set_env_params(mpopis_handle* h, const double* p, int32_t n) {
 }
 
 int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const double* w, int32_t P) {
-    if (!h || !x || !y || !w || P < 2) { if (h) h->err = "bad track"; return MPOPIS_ERR_ARG; }
+    if (!h || !x || !y || !w || P < 2 || P > 2048) { if (h) h->err = "bad track (need 2 <= P <= 2048 points)"; return MPOPIS_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     double* d = nullptr;
     if (dalloc(h, &d, (size_t)3 * P)) return MPOPIS_ERR_HIP;
@@ -256,12 +257,12 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     if (!h || !Sigma) return MPOPIS_ERR_ARG;
     const int cs = h->cs, as = h->as;
     std::vector<double> full((size_t)cs * cs, 0.0);
-    if (n == as && !(n == cs && h->cfg.policy != MPOPIS_POL_MPPI && as == cs)) {
+    if (n == cs && h->cfg.policy != MPOPIS_POL_MPPI) {
+        memcpy(full.data(), Sigma, sizeof(double) * cs * cs);
+    } else if (n == as) {
         for (int t = 0; t < h->T; ++t)
             for (int j = 0; j < as; ++j)
                 for (int i = 0; i < as; ++i) full[(size_t)(t * as + i) + (size_t)(t * as + j) * cs] = Sigma[i + (size_t)j * as];
-    } else if (n == cs && h->cfg.policy != MPOPIS_POL_MPPI) {
-        memcpy(full.data(), Sigma, sizeof(double) * cs * cs);
     } else { h->err = "Covariance matrix size problem"; return MPOPIS_ERR_ARG; }     // :79
     bool diag = true;
     for (int j = 0; j < cs && diag; ++j) for (int i = 0; i < cs; ++i) if (i != j && full[(size_t)i + (size_t)j * cs] != 0.0) { diag = false; break; }
@@ -310,6 +311,7 @@ int mpopis_rollout_costs(mpopis_handle* h, const double* x0, const double* U, co
         gv = h->d_gvec;
     }
     fill_i32(h->d_status, 0, B, h->stream);
+    h->prepare_state();
     h->rollout(h->d_Ucur, h->d_Uin, gv, nullptr);
     HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -440,10 +442,14 @@ int mpopis_bench_policy_steps(mpopis_handle* h, int32_t steps, double* ms, doubl
 }  // extern "C"
 
 // ---- launch sequences -----------------------------------------------------------------------------
+void mpopis_handle::prepare_state() {
+    if (env.kind == MPOPIS_ENV_CAR) launch_extend_state(d_x, d_xext, B, env.ncars, stream);
+}
+
 void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act) {
     RolloutArgs a;
     a.env = env; a.B = B; a.K = K; a.T = T; a.cs = cs;
-    a.x0 = d_x; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
+    a.x0 = d_x; a.x0ext = d_xext; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
     a.cost = d_cost; a.traj = d_traj; a.active = act;
     time_begin(0);
     launch_rollout(a, stream);
@@ -459,6 +465,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     fill_i32(d_status, 0, B, stream);
     fill_i32(d_active, 1, B, stream);
     fill_i32(d_iters, 0, B, stream);
+    prepare_state();
     // U_orig = pol.U  (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop)
     copy_f64(d_U, d_Uin, (size_t)B * cs, stream);
     copy_f64(d_U, d_Ucur, (size_t)B * cs, stream);

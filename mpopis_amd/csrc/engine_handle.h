@@ -11,7 +11,7 @@ struct mpopis_handle {
     std::string err;
     std::vector<void*> allocs;
     // resident env + policy state
-    double *d_x = nullptr, *d_U = nullptr, *d_Ucur = nullptr, *d_Uin = nullptr;
+    double *d_x = nullptr, *d_xext = nullptr, *d_U = nullptr, *d_Ucur = nullptr, *d_Uin = nullptr;
     int *d_t = nullptr, *d_done = nullptr;
     // proposal
     double *d_Sigma0 = nullptr, *d_L0 = nullptr, *d_dscale0 = nullptr;   // shared pol.Σ, its factor, sqrt(diag)
@@ -40,6 +40,7 @@ struct mpopis_handle {
 
     void time_begin(int slot);
     void time_end();
+    void prepare_state();
     void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act);
     int policy_step_enqueue(bool injected);
     int ais_update(int n, bool injected);

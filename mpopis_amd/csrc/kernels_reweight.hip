@@ -165,11 +165,11 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
         if (NC == 1 && !(a0 >= env.lo[0] && a0 <= env.hi[0] && a1 >= env.lo[1] && a1 <= env.hi[1])) {
             if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION);                // car_racing.jl:239
         }
-        double s[8];
-        for (int i = 0; i < 8; ++i) s[i] = xb[8 * c + i];
+        CarState s;
+        car_state_from8(s, xb + 8 * c);
         car_action_step(env.car, s, a0, a1);
-        for (int i = 0; i < 8; ++i) xb[8 * c + i] = s[i];
-        srew[c] = car_reward(env.car, env.track, s);
+        car_state_to8(s, xb + 8 * c);
+        srew[c] = car_reward(env.car, env.track, s.x, s.y, s.Vx, s.Vy);
     }
     __syncthreads();
     if (c == 0) {

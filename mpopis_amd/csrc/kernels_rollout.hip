@@ -29,12 +29,23 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
     const bool valid = k < K;
     const int kk = valid ? k : K - 1;
     constexpr int as = 2 * NC, ss = 8 * NC;
+    (void)ss;
 
     const CarParams& p = a.env.car;
-    const Track tk = a.env.track;
-    double s[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = a.x0[b * ss + 8 * c + i];
+    // stage the (wave-uniform, read-only) track in LDS: uniform-address ds_reads broadcast to all lanes
+    extern __shared__ __attribute__((aligned(16))) double sh_trk[];
+    const int P = a.env.track.P;
+    for (int i = threadIdx.x; i < P; i += 64 * NC) {
+        sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
+    }
+    __syncthreads();
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, P};
+    CarState s;                                               // wave-uniform start state (+ sin/cos), scalar loads
+    {
+        const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
+        s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
+        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11];
+    }
     const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
     const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
     const double* Uo = a.Uorig + (size_t)b * a.cs + 2 * c;
@@ -53,16 +64,16 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
         const double a0 = clampd(v0, lo0, hi0), a1 = clampd(v1, lo1, hi1);     // get_model_controls
         car_action_step(p, s, a0, a1);
-        double rew = car_reward(p, tk, s);
+        double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy);
         if (NC > 1) {                                                          // multi-car_racing.jl:145-158
             const int buf = t & 1;
-            sh_xy[buf][c][0][lane] = s[0];
-            sh_xy[buf][c][1][lane] = s[1];
+            sh_xy[buf][c][0][lane] = s.x;
+            sh_xy[buf][c][1][lane] = s.y;
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 if (j > c) {
-                    const double dx = sh_xy[buf][j][0][lane] - s[0], dy = sh_xy[buf][j][1][lane] - s[1];
+                    const double dx = sh_xy[buf][j][0][lane] - s.x, dy = sh_xy[buf][j][1][lane] - s.y;
                     const double dd = sqrt(dx * dx + dy * dy);
                     rew += -dd;
                     if (dd <= 4.0) rew += -11000.0;
@@ -70,9 +81,11 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
             }
         }
         cost -= rew;                                                           // utils.jl:138
-        if (tr && valid) {
+        if (tr && valid) {                                                     // trajectories[k][t, :] utils.jl:140
+            double s8[8];
+            car_state_to8(s, s8);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) tr[(size_t)(8 * c + i) * T + t] = s[i];   // trajectories[k][t, :] utils.jl:140
+            for (int i = 0; i < 8; ++i) tr[(size_t)(8 * c + i) * T + t] = s8[i];
         }
     }
     cost += cc;
@@ -117,17 +130,34 @@ __global__ void __launch_bounds__(64) k_rollout_mountaincar(RolloutArgs a) {
     if (valid) a.cost[(size_t)b * K + k] = cost + cc;
 }
 
+// x0ext[b][car][12] = env state + sin/cos(psi), sin/cos(delta): evaluated once per trial and car
+// instead of once per sample (the start state is shared by all K rollouts).
+__global__ void k_extend_state(const double* x, double* xext, int n_cars_total) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_cars_total) return;
+    CarState c;
+    car_state_from8(c, x + (size_t)i * 8);
+    double* o = xext + (size_t)i * kCarExt;
+    o[0] = c.x; o[1] = c.y; o[2] = c.psi; o[3] = c.Vx; o[4] = c.Vy; o[5] = c.r; o[6] = c.delta; o[7] = c.pedal;
+    o[8] = c.sp; o[9] = c.cp; o[10] = c.sd; o[11] = c.cd;
+}
+void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t st) {
+    const int n = B * ncars;
+    hipLaunchKernelGGL(k_extend_state, dim3((n + 63) / 64), dim3(64), 0, st, x, xext, n);
+}
+
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     dim3 grid((a.K + 63) / 64, a.B);
     if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
         hipLaunchKernelGGL(k_rollout_mountaincar, grid, dim3(64), 0, st, a);
         return;
     }
+    const size_t lds = (size_t)3 * a.env.track.P * sizeof(double);
     switch (a.env.ncars) {
-        case 1: hipLaunchKernelGGL(k_rollout_car<1>, grid, dim3(64), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(k_rollout_car<2>, grid, dim3(128), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(k_rollout_car<3>, grid, dim3(192), 0, st, a); break;
-        case 4: hipLaunchKernelGGL(k_rollout_car<4>, grid, dim3(256), 0, st, a); break;
+        case 1: hipLaunchKernelGGL(k_rollout_car<1>, grid, dim3(64), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(k_rollout_car<2>, grid, dim3(128), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(k_rollout_car<3>, grid, dim3(192), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(k_rollout_car<4>, grid, dim3(256), lds, st, a); break;
         default: break;
     }
 }

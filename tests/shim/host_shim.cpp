@@ -6,12 +6,14 @@ using namespace mpopis;
 extern "C" {
 void shim_car_action_step(const double* p20, double* s8, double a0, double a1) {
     CarParams p = make_car_params(p20);
-    car_action_step(p, s8, a0, a1);
+    CarState c; car_state_from8(c, s8);
+    car_action_step(p, c, a0, a1);
+    car_state_to8(c, s8);
 }
 double shim_car_reward(const double* p20, int P, const double* tx, const double* ty, const double* tw, const double* s8) {
     CarParams p = make_car_params(p20);
     Track tk{tx, ty, tw, P};
-    return car_reward(p, tk, s8);
+    return car_reward(p, tk, s8[0], s8[1], s8[3], s8[4]);
 }
 // full single-car rollout: controls as x T (already clamped); returns -sum(reward)
 double shim_car_rollout(const double* p20, int P, const double* tx, const double* ty, const double* tw,
@@ -19,7 +21,9 @@ double shim_car_rollout(const double* p20, int P, const double* tx, const double
     CarParams p = make_car_params(p20);
     Track tk{tx, ty, tw, P};
     double c = 0.0;
-    for (int t = 0; t < T; ++t) { car_action_step(p, s8, ctrl[2 * t], ctrl[2 * t + 1]); c -= car_reward(p, tk, s8); }
+    CarState st; car_state_from8(st, s8);          // sin/cos evaluated once, then carried (as in the kernel)
+    for (int t = 0; t < T; ++t) { car_action_step(p, st, ctrl[2 * t], ctrl[2 * t + 1]); c -= car_reward(p, tk, st.x, st.y, st.Vx, st.Vy); }
+    car_state_to8(st, s8);
     return c;
 }
 void shim_mc_step(const double* p8, double* s2, int* t, int* done, double f) { McParams p = make_mc_params(p8); mc_step(p, s2, t, done, f); }
