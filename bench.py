@@ -1,0 +1,153 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MPOPIS rollout-and-reweight path on MI355X.
+
+Workload (BASELINE.json configs[4] per GPU share): Car-Racing 1-car :μΣaismppi, K=4096, H=50,
+N=10 AIS iterations, 8 independent trials resident per GPU (64 trials / 8 GPUs; weak scaling:
+N GPUs run 8N trials).  One "step" = one MPC step of every resident trial = 8*10*4096 model
+rollouts + 10 reweightings + 9 (mu, Sigma) updates.  Metric: trajectory rollouts/s (whole job) and
+MPC steps/s.  Noise comes from the device Philox streams; inputs are resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K, H, N_AIS, CARS = 4096, 50, 10, 1
+TRIALS_PER_GPU = 8
+LAM, LAM_AIS = 10.0, 20.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6        # FP64 vector (public spec)
+BYTES_PER_ROLLOUT = 8 * (4 * 2 * CARS * H + 4)      # 3232 B (Σ-adapting iterations, cs=100)
+FLOPS_PER_ROLLOUT = 3.5e5 * CARS                    # SURVEY 8(d) reference-algorithm flop-equivalents
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle (C restatement, OpenMP over k like Threads.@threads :269) on this box's host cores,
+    same workload: whole pol(env) steps of ONE trial, bounded to ~10-30 s of CPU work."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    track = O.load_track()
+    env = O.OracleEnv("car", CARS, track=track)
+    pol = O.OraclePolicy("musigmaaismppi", env, K, H, lam=LAM, U0=np.zeros(2 * CARS), cov=np.tile([0.0625, 0.1], CARS),
+                         N=N_AIS, lam_ais=LAM_AIS, nthreads=cores)
+    cs = 2 * CARS * H
+    steps, t_total = 0, 0.0
+    while True:
+        Z = np.stack([O.philox_normals(20240001, steps, n, cs * K).reshape(K, cs) for n in range(N_AIS)])
+        t0 = time.perf_counter()
+        r = pol(env, Z)
+        t_total += time.perf_counter() - t0
+        assert r["status"] == 0
+        steps += 1
+        if t_total >= seconds_target or steps >= 64:
+            break
+    rollouts = steps * N_AIS * K
+    return {"value": rollouts / t_total, "unit": "rollouts/s", "cores": cores, "kind": "port",
+            "sample": "%d MPC step(s) of 1 trial, same config (%d rollouts), C oracle + OpenMP over k, %.1f s" % (steps, rollouts, t_total),
+            "mpc_steps_per_s": steps / t_total}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+
+    from mpopis_amd import build
+    if rank == 0:
+        build.build()
+    if dist is not None:
+        dist.barrier()
+    from mpopis_amd.engine import Engine
+    B = args.trials_per_gpu
+    # trial slot b on rank g is global trial g*B+b: seeds 20240000 + trial + 1 (seed+k, car_example.jl:187-188)
+    eng = Engine("car", CARS, "μΣaismppi", K, H, batch=B, lam=LAM, alpha=1.0, ais_its=N_AIS, lam_ais=LAM_AIS,
+                 cov=np.tile([0.0625, 0.1], CARS), seed=20240000 + rank * B, device=local_rank)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.bench_policy_steps(args.warmup)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    sync()
+    t0 = time.perf_counter()
+    ms_dev, rollouts = eng.bench_policy_steps(args.steps)
+    # summary stats only: per-trial record (control + mean cost) gathered to rank 0 over RCCL
+    if dist is not None:
+        rec = torch.zeros(B, 4, device="cuda", dtype=torch.float64)
+        gl = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
+        dist.gather(rec, gl, dst=0)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    tm = eng.timing_read()
+    eng.timing_enable(False)
+
+    if rank == 0:
+        total_rollouts = rollouts * world
+        value = total_rollouts / dt
+        r_ms, r_n = tm["rollout"]
+        r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
+        per_launch = B * K
+        ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
+        ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "trajectory rollouts/sec (+ MPC steps/sec), Car-Racing K=4096 H=50",
+            "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "mpc_steps_per_s": B * world * args.steps / dt,
+            "config": {"workload": "Car-Racing 1-car :μΣaismppi K=4096 H=50 N=10 λ=10 λ_ais=20, %d trials/GPU (BASELINE configs[4]: 64 trials / 8 GPUs)" % B,
+                       "trials_per_gpu": B, "rollouts_per_step": int(B * N_AIS * K), "parallelism": "trials sharded x%d, RCCL gather of summary stats" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
+                         "binding_resource": "FP64 VALU (not HBM): see fp64_*",
+                         "fp64_achieved_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS, "fp64_frac": ach_tf / FP64_PEAK_TFLOPS},
+            "kernel_ms": {k: v[0] for k, v in tm.items() if v[1]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out, ensure_ascii=False))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
