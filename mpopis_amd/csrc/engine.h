@@ -93,4 +93,24 @@ void launch_wcov(const double* X, const double* w, const int32_t* idx, int m, co
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);
 
+
+void launch_gather_mean_strided(const double* X, const int32_t* idx, const double* cw, double* out, size_t out_stride, int B, int cs, int K, int m,
+                                const int* active, hipStream_t s);
+
+// kernels_select.hip
+void launch_sortperm(const double* cost, int32_t* order, int B, int K, const int* active, hipStream_t s);
+void launch_elite_break(const double* cost, const int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s);
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s);
+void launch_alias_sample(const double* accept, const int32_t* alias, const int32_t* di, size_t di_stride, const double* du,
+                         int32_t* out, int32_t* log, size_t log_stride, int B, int K, const int* active, hipStream_t s);
+
+// kernels_cma.hip
+void launch_inv_sqrt_spd(const double* A, double* C, double* Y0, double* Y1, double* Z0, double* Z1, double* Tm, double* cnorm,
+                         unsigned long long* resid, int B, int n, int iters, const int* active, hipStream_t s);
+void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, int cs, int B, hipStream_t s);
+void launch_cma_paths(const double* C, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
+                      double* sig2, int B, int cs, int K, int n_iter, const double* consts7, int m_elite, const int* active, hipStream_t s);
+void launch_cma_sigma_update(double* Sig, const double* scal, const double* vec, int B, int cs, const double* consts7, int m_elite,
+                             const int* active, hipStream_t s);
+
 }  // namespace mpopis

@@ -27,12 +27,35 @@ __global__ void __launch_bounds__(256) k_add_active(const double* x, double* y, 
 
 }  // namespace mpopis
 
-void mpopis_handle::init_cma_constants() {}
-void mpopis_handle::cma_begin() {}
-const double* mpopis_handle::cma_sigma2() { return nullptr; }
+// CMAMPPI_Policy constructor constants: src/mppi_mpopi_policies.jl:513-525
+void mpopis_handle::init_cma_constants() {
+    const int m = K; const double n = (double)cs;
+    m_elite = (int)nearbyint((1.0 - cfg.elite_threshold) * m);
+    cma_ws_host.resize(m);
+    for (int i = 1; i <= m; ++i) cma_ws_host[i - 1] = log((m + 1) / 2.0) - log((double)i);
+    double s = 0.0;
+    for (int i = 0; i < m_elite; ++i) s += cma_ws_host[i];
+    for (int i = 0; i < m_elite; ++i) cma_ws_host[i] /= s;
+    double s2 = 0.0;
+    for (int i = 0; i < m_elite; ++i) s2 += cma_ws_host[i] * cma_ws_host[i];
+    const double mu_eff = 1 / s2;
+    const double c_sigma = (mu_eff + 2) / (n + mu_eff + 5);
+    const double d_sigma = 1 + 2 * fmax(0.0, sqrt((mu_eff - 1) / (n + 1)) - 1) + c_sigma;
+    const double c_Sigma = (4 + mu_eff / n) / (n + 4 + 2 * mu_eff / n);
+    const double c1 = 2 / ((n + 1.3) * (n + 1.3) + mu_eff);
+    const double c_mu = fmin(1 - c1, 2 * (mu_eff - 2 + 1 / mu_eff) / ((n + 2) * (n + 2) + mu_eff));
+    double st = 0.0;
+    for (int i = m_elite; i < m; ++i) st += cma_ws_host[i];
+    const double f = -(1 + c1 / c_mu) / st;
+    for (int i = m_elite; i < m; ++i) cma_ws_host[i] *= f;
+    const double E_cma = sqrt(n) * (1 - 1 / (4 * n) + 1 / (21 * (n * n)));
+    const double c[7] = {mu_eff, c_sigma, d_sigma, c_Sigma, c1, c_mu, E_cma};
+    for (int i = 0; i < 7; ++i) cma_consts[i] = c[i];
+}
+void mpopis_handle::cma_begin() { launch_cma_begin(d_cma_scal, d_cma_vec, d_sig2, cfg.cma_sigma, cs, B, stream); }
+const double* mpopis_handle::cma_sigma2() { return d_sig2; }
 
 int mpopis_handle::ais_update(int n, bool injected) {
-    (void)n; (void)injected;
     const int pol = cfg.policy;
     if (pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI || pol == MPOPIS_POL_MUSIGMAAISMPPI) {
         const double lam = (pol == MPOPIS_POL_IMPPI) ? cfg.lambda : cfg.lambda_ais;          // :362 / :647,:712
@@ -48,7 +71,51 @@ int mpopis_handle::ais_update(int n, bool injected) {
         hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);   // pol.U += μ′
         return MPOPIS_OK;
     }
-    err = "policy update not implemented yet";
+    if (pol == MPOPIS_POL_PMCMPPI) {                                                          // :802-809
+        time_begin(3);
+        launch_weights(d_cost, d_w, B, K, cfg.lambda_ais, d_active, d_status, stream);
+        time_end();
+        time_begin(5);
+        launch_alias_build(d_w, d_accept, d_alias, B, K, d_active, stream);                   // Categorical(ws) -> AliasTable
+        const int32_t* di; const double* du; size_t stride;
+        if (injected) { di = d_resi_in + (size_t)(n - 1) * K; du = d_resu_in + (size_t)(n - 1) * K; stride = (size_t)(N - 1) * K; }
+        else {
+            launch_sample_resample_draws(d_resi, d_resu, B, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1) | 0x80000000u, d_active, stream);
+            di = d_resi; du = d_resu; stride = (size_t)K;
+        }
+        launch_alias_sample(d_accept, d_alias, di, stride, du, d_order, d_residx_log + (size_t)(n - 1) * K, (size_t)(N - 1) * K, B, K, d_active, stream);
+        time_end();
+        time_begin(4);
+        launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, K, 1, d_active, stream);   // mean_and_cov(E[:,idx], 2): corrected
+        launch_wcov(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream);
+        time_end();
+        hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
+        return MPOPIS_OK;
+    }
+    if (pol == MPOPIS_POL_CEMPPI || pol == MPOPIS_POL_CMAMPPI) {
+        time_begin(5);
+        launch_sortperm(d_cost, d_order, B, K, d_active, stream);                             // :455 / :563
+        launch_elite_break(d_cost, d_order, B, K, m_elite, d_active, stream);                 // :458-461 / :566-569
+        time_end();
+        if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
+            if (cfg.sigma_est != MPOPIS_SIGMA_EST_MLE) { err = "Σ_est :ss is not implemented on the device yet (use :mle)"; return MPOPIS_ERR_ARG; }
+            time_begin(4);
+            launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
+            launch_wcov(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
+            time_end();
+            hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
+            return MPOPIS_OK;
+        }
+        time_begin(4);
+        double* dw = d_cma_vec + 2 * (size_t)cs;                                              // δw slot of slot 0; stride 3cs
+        launch_gather_mean_strided(d_E, d_order, d_cma_ws, dw, (size_t)3 * cs, B, cs, K, m_elite, d_active, stream);   // :573-576
+        launch_inv_sqrt_spd(d_Sig, d_C, d_Y0, d_Y1, d_Z0, d_Z1, d_Tm, d_cnorm, d_resid, B, cs, kNsIters, d_active, stream);   // C = Σ^-0.5 :580
+        launch_cma_paths(d_C, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
+        launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);
+        time_end();
+        return MPOPIS_OK;
+    }
+    err = "policy update not implemented";
     return MPOPIS_ERR_ARG;
 }
 

@@ -138,8 +138,13 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
     h->ksplit = std::max(1, std::min(16, K / 256));
     rc |= dalloc(h, &h->d_part, wcov_workspace_doubles(B, cs, h->ksplit));
-    rc |= dalloc(h, &h->d_cma, (size_t)B * (3 * cs + 8)); rc |= dalloc(h, &h->d_cma_ws, (size_t)K);
-    rc |= dalloc(h, &h->d_C, (size_t)B * nn); rc |= dalloc(h, &h->d_Y, (size_t)B * nn); rc |= dalloc(h, &h->d_Tm, (size_t)B * nn);
+    if (cfg->policy == MPOPIS_POL_CMAMPPI) {
+        rc |= dalloc(h, &h->d_cma_scal, (size_t)B * 8); rc |= dalloc(h, &h->d_cma_vec, (size_t)B * 3 * cs); rc |= dalloc(h, &h->d_sig2, B);
+        rc |= dalloc(h, &h->d_cma_ws, (size_t)K); rc |= dalloc(h, &h->d_cnorm, B);
+        rc |= dalloc(h, &h->d_C, (size_t)B * nn); rc |= dalloc(h, &h->d_Y0, (size_t)B * nn); rc |= dalloc(h, &h->d_Y1, (size_t)B * nn);
+        rc |= dalloc(h, &h->d_Z0, (size_t)B * nn); rc |= dalloc(h, &h->d_Z1, (size_t)B * nn); rc |= dalloc(h, &h->d_Tm, (size_t)B * nn);
+        rc |= dalloc(h, &h->d_resid, (size_t)(mpopis_handle::kNsIters + 1) * B);
+    }
     if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     h->h_status.assign(B, 0);
@@ -150,8 +155,14 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (mpopis_set_Sigma(h, eye.data(), n0) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     if (mpopis_seed(h, cfg->seed) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     if (mpopis_reset(h) != 0) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
-    if (cfg->policy == MPOPIS_POL_CMAMPPI) h->init_cma_constants();
+    if (cfg->policy == MPOPIS_POL_CMAMPPI) {
+        h->init_cma_constants();
+        if ((long long)cs * h->m_elite < K) { g_create_error = "BoundsError: δs[order[ii]] needs cs*m_elite >= K (src/mppi_mpopi_policies.jl:593)"; mpopis_destroy(h); return MPOPIS_ERR_ARG; }
+        if (hipMemcpy(h->d_cma_ws, h->cma_ws_host.data(), sizeof(double) * K, hipMemcpyHostToDevice) != hipSuccess) { g_create_error = "upload failed"; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    }
     if (cfg->policy == MPOPIS_POL_CEMPPI) h->m_elite = (int)nearbyint(K * (1 - cfg->elite_threshold));   // :437
+    if ((cfg->policy == MPOPIS_POL_CEMPPI || cfg->policy == MPOPIS_POL_CMAMPPI) && K > 8192) { g_create_error = "cemppi/cmamppi: K <= 8192 supported"; mpopis_destroy(h); return MPOPIS_ERR_ARG; }
+    if (cfg->policy == MPOPIS_POL_PMCMPPI && K > 7168) { g_create_error = "pmcmppi: K <= 7168 supported"; mpopis_destroy(h); return MPOPIS_ERR_ARG; }
     *out = h;
     return MPOPIS_OK;
 }

@@ -29,8 +29,12 @@ struct mpopis_handle {
     double* d_part = nullptr; int ksplit = 1;
     // CMA (src/mppi_mpopi_policies.jl:513-525 constants; :536-545 per-call state)
     int m_elite = 0;
-    double mu_eff = 0, c_sigma = 0, d_sigma = 0, c_Sigma = 0, c1 = 0, c_mu = 0, E_cma = 0;
-    double *d_cma = nullptr, *d_cma_ws = nullptr, *d_C = nullptr, *d_Y = nullptr, *d_Tm = nullptr;
+    double cma_consts[7] = {0, 0, 0, 0, 0, 0, 0};    // mu_eff, cσ, dσ, cΣ, c1, cμ, E
+    std::vector<double> cma_ws_host;
+    double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr, *d_cnorm = nullptr;
+    double *d_C = nullptr, *d_Y0 = nullptr, *d_Y1 = nullptr, *d_Z0 = nullptr, *d_Z1 = nullptr, *d_Tm = nullptr;
+    unsigned long long* d_resid = nullptr;
+    static constexpr int kNsIters = 28;
     // bookkeeping
     uint64_t mpc_step = 0;
     std::vector<int> h_status;

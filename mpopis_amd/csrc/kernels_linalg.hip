@@ -277,7 +277,7 @@ void launch_wcov(const double* X, const double* w, const int32_t* idx, int m, co
 
 // mean over gathered columns: mu[r] = (1/m) Σ_j X[r][idx[j]] ; optionally weighted by cw[j] (CMA δw, no division)
 __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ X, const int32_t* __restrict__ idx, const double* __restrict__ cw,
-                                                     double* __restrict__ mu, int cs, int K, int m, int divide, const int* active) {
+                                                     double* __restrict__ mu, size_t mu_stride, int cs, int K, int m, int divide, const int* active) {
     const int b = blockIdx.y, r = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[4];
@@ -289,11 +289,15 @@ __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) { double t = sh[0] + sh[1] + sh[2] + sh[3]; mu[(size_t)b * cs + r] = divide ? t / m : t; }
+    if (threadIdx.x == 0) { double t = sh[0] + sh[1] + sh[2] + sh[3]; mu[(size_t)b * mu_stride + r] = divide ? t / m : t; }
 }
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_mean, dim3(cs, B), dim3(256), 0, s, X, idx, cw, mu, cs, K, m, divide, active);
+    hipLaunchKernelGGL(k_gather_mean, dim3(cs, B), dim3(256), 0, s, X, idx, cw, mu, (size_t)cs, cs, K, m, divide, active);
+}
+void launch_gather_mean_strided(const double* X, const int32_t* idx, const double* cw, double* out, size_t out_stride, int B, int cs, int K, int m,
+                                const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_mean, dim3(cs, B), dim3(256), 0, s, X, idx, cw, out, out_stride, cs, K, m, 0, active);
 }
 
 }  // namespace mpopis

@@ -1,0 +1,138 @@
+// kernels_select.hip -- order statistics and multinomial resampling on device:
+//   order = sortperm(trajectory_cost)                       src/mppi_mpopi_policies.jl:455,563
+//   early break: maximum(abs.(diff(elite_traj_cost))) < 10e-3   :458-461,:566-569
+//   Categorical(ws) -> AliasTable (StatsBase.make_alias_table!) + rand(rng, ., K)   :804-805
+// One workgroup per trial slot; K <= 8192 (sort) / K <= 7168 (alias) live entirely in LDS.
+#include "engine.h"
+
+namespace mpopis {
+
+// Bitonic sort of (cost, index) pairs under the total order (cost asc, index asc) == Julia's stable
+// sortperm.  n = next pow2 >= K, padded with (+inf, big index).
+__global__ void __launch_bounds__(1024) k_sortperm(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int n,
+                                                   const int* active) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* key = reinterpret_cast<double*>(smem);
+    int32_t* idx = reinterpret_cast<int32_t*>(smem + (size_t)n * sizeof(double));
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { key[i] = (i < K) ? cost[(size_t)b * K + i] : INFINITY; idx[i] = i; }
+    __syncthreads();
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < n / 2; t += blockDim.x) {
+                const int lo = 2 * t - (t & (stride - 1));          // index with the `stride` bit clear
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const double ka = key[lo], kb = key[hi];
+                const int ia = idx[lo], ib = idx[hi];
+                const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+                if (a_gt_b == up) { key[lo] = kb; key[hi] = ka; idx[lo] = ib; idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += blockDim.x) order[(size_t)b * K + i] = idx[i];
+}
+
+void launch_sortperm(const double* cost, int32_t* order, int B, int K, const int* active, hipStream_t s) {
+    int n = 1;
+    while (n < K) n <<= 1;
+    const size_t bytes = (size_t)n * (sizeof(double) + sizeof(int32_t));
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_sortperm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_sortperm, dim3(B), dim3(n >= 2048 ? 1024 : 256), bytes, s, cost, order, K, n, active);
+}
+
+// CE/CMA early break: if max_j |c[order[j+1]] - c[order[j]]| < 10e-3 over the elite set, the slot
+// leaves the AIS loop (active[b] = 0) -- nothing of this iteration's update is applied.
+__global__ void __launch_bounds__(256) k_elite_break(const double* __restrict__ cost, const int32_t* __restrict__ order, int K, int m_elite,
+                                                     int* active) {
+    const int b = blockIdx.x;
+    if (!active[b]) return;
+    __shared__ double sh[4];
+    double mx = -INFINITY;
+    for (int j = threadIdx.x; j + 1 < m_elite; j += 256)
+        mx = fmax(mx, fabs(cost[(size_t)b * K + order[(size_t)b * K + j + 1]] - cost[(size_t)b * K + order[(size_t)b * K + j]]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        if (m_elite >= 2 && mx < 10e-3) active[b] = 0;
+    }
+}
+void launch_elite_break(const double* cost, const int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_elite_break, dim3(B), dim3(256), 0, s, cost, order, K, m_elite, active);
+}
+
+// StatsBase.make_alias_table!(w, 1.0, a, alias): Vose's construction with LIFO stacks of smalls and
+// larges, executed in the reference's exact operation order (the result must be bit-identical for
+// identical w).  Wave 0 classifies with ballots (keeps index order); lane 0 runs the sequential
+// pairing loop keeping the current large in registers (LIFO => it is re-popped immediately).
+__global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
+                                                    int K, const int* active) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* a = reinterpret_cast<double*>(smem);
+    int32_t* al = reinterpret_cast<int32_t*>(smem + (size_t)K * 8);
+    int32_t* larges = al + K;
+    int32_t* smalls = larges + K;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int lane = threadIdx.x;
+    const double ac = (double)K / 1.0;                          // n / wsum
+    int kl = 0, ks = 0;
+    for (int i0 = 0; i0 < K; i0 += 64) {
+        const int i = i0 + lane;
+        const double ai = (i < K) ? w[(size_t)b * K + i] * ac : 1.0;
+        if (i < K) { a[i] = ai; al[i] = i; }
+        const unsigned long long ml = __ballot(ai > 1.0), ms = __ballot(ai < 1.0);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (ai > 1.0) larges[kl + __popcll(ml & lt)] = i;
+        else if (ai < 1.0) smalls[ks + __popcll(ms & lt)] = i;
+        kl += __popcll(ml); ks += __popcll(ms);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        while (kl > 0 && ks > 0) {
+            const int s = smalls[--ks];
+            const int l = larges[--kl];
+            al[s] = l;
+            const double alv = (a[l] - 1.0) + a[s];
+            a[l] = alv;
+            if (alv > 1.0) larges[kl++] = l; else smalls[ks++] = l;
+        }
+        for (int i = 0; i < ks; ++i) a[smalls[i]] = 1.0;
+    }
+    __syncthreads();
+    for (int i = lane; i < K; i += 64) { accept[(size_t)b * K + i] = a[i]; alias[(size_t)b * K + i] = al[i]; }
+}
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s) {
+    const size_t bytes = (size_t)K * (8 + 4 + 4 + 4);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_alias_build, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_alias_build, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active);
+}
+
+// rand(rng, s::AliasTable): i = rand(1:n); u = rand(); u < accept[i] ? i : alias[i]
+__global__ void __launch_bounds__(256) k_alias_sample(const double* __restrict__ accept, const int32_t* __restrict__ alias,
+                                                      const int32_t* __restrict__ di, size_t di_stride, const double* __restrict__ du,
+                                                      int32_t* __restrict__ out, int32_t* __restrict__ log, size_t log_stride, int K,
+                                                      const int* active) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int i = di[(size_t)b * di_stride + k];
+    const double u = du[(size_t)b * di_stride + k];
+    const int r = (u < accept[(size_t)b * K + i]) ? i : alias[(size_t)b * K + i];
+    out[(size_t)b * K + k] = r;
+    if (log) log[(size_t)b * log_stride + k] = r;
+}
+void launch_alias_sample(const double* accept, const int32_t* alias, const int32_t* di, size_t di_stride, const double* du,
+                         int32_t* out, int32_t* log, size_t log_stride, int B, int K, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_alias_sample, dim3((K + 255) / 256, B), dim3(256), 0, s, accept, alias, di, di_stride, du, out, log, log_stride, K, active);
+}
+
+}  // namespace mpopis
