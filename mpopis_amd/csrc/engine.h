@@ -73,7 +73,7 @@ void launch_transpose_out(const double* src_rows, const double* shiftA, const do
 
 // real env step + reward for the resident envs
 void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action,
-                     double* reward, int* status, int B, hipStream_t s);
+                     double* reward, int* status, const int* alive, int B, hipStream_t s);
 
 // kernels_sample.hip
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,

@@ -119,4 +119,3 @@ int mpopis_handle::ais_update(int n, bool injected) {
     return MPOPIS_ERR_ARG;
 }
 
-int mpopis_handle::run_trials(int, int, double*, double*) { err = "run_trials not implemented yet"; return MPOPIS_ERR_ARG; }

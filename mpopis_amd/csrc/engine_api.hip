@@ -336,7 +336,7 @@ int mpopis_env_step(mpopis_handle* h, const double* action, double* reward) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_control, action, sizeof(double) * h->B * h->as, hipMemcpyHostToDevice, h->stream));
     fill_i32(h->d_status, 0, h->B, h->stream);
-    launch_env_step(h->env, h->d_x, h->d_t, h->d_done, h->d_control, h->d_reward, h->d_status, h->B, h->stream);
+    launch_env_step(h->env, h->d_x, h->d_t, h->d_done, h->d_control, h->d_reward, h->d_status, nullptr, h->B, h->stream);
     if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, sizeof(double) * h->B, hipMemcpyDeviceToHost, h->stream));
     return sync_status(h);
 }
@@ -473,8 +473,9 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     const int pol = cfg.policy;
     const size_t nn = (size_t)cs * cs, per = (size_t)cs * K;
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
-    fill_i32(d_status, 0, B, stream);
-    fill_i32(d_active, 1, B, stream);
+    if (!status_sticky) fill_i32(d_status, 0, B, stream);
+    if (alive_gate) (void)hipMemcpyAsync(d_active, alive_gate, sizeof(int) * B, hipMemcpyDeviceToDevice, stream);   // frozen trials stay out
+    else fill_i32(d_active, 1, B, stream);
     fill_i32(d_iters, 0, B, stream);
     prepare_state();
     // U_orig = pol.U  (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop)
@@ -524,8 +525,8 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     }
     // weights = compute_weights(IT(λ), cost); weighted_noise = Σ_k w_k (E_k + (pol.U - U_orig)); roll
     time_begin(3);
-    launch_weights(d_cost, d_w, B, K, cfg.lambda, nullptr, d_status, stream);
-    launch_wmean(d_E, d_w, d_Ucur, d_Uin, d_wn, B, cs, K, 0, nullptr, stream);
+    launch_weights(d_cost, d_w, B, K, cfg.lambda, alive_gate, d_status, stream);
+    launch_wmean(d_E, d_w, d_Ucur, d_Uin, d_wn, B, cs, K, 0, alive_gate, stream);
     launch_finalize_env(d_wn, d_U, d_control, B, cs, as, T, env, stream);
     time_end();
     mpc_step += 1;

@@ -144,8 +144,9 @@ void launch_transpose_out(const double* src, const double* shiftA, const double*
 
 // env(action); reward(env) for the resident real envs (one workgroup per slot, lane c = car c)
 __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t, int* done, const double* action,
-                                                 double* reward, int* status) {
+                                                 double* reward, int* status, const int* alive) {
     const int b = blockIdx.x, c = threadIdx.x;
+    if (alive && !alive[b]) return;
     __shared__ double srew[kMaxCars];
     if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
         if (c == 0) {
@@ -189,8 +190,8 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
         }
     }
 }
-void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action, double* reward, int* status, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_env_step, dim3(B), dim3(64), 0, s, env, x, t, done, action, reward, status);
+void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action, double* reward, int* status, const int* alive, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_step, dim3(B), dim3(64), 0, s, env, x, t, done, action, reward, status, alive);
 }
 
 }  // namespace mpopis

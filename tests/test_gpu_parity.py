@@ -212,3 +212,38 @@ def test_env_step_and_errors(eng_mod, oracle, track):
         eng.set_Sigma(np.eye(3))                           # "Covariance matrix size problem" :79
     assert ei.value.code == -1
     eng.close()
+
+
+@pytest.mark.parametrize("kind,K,T,N", [("cemppi", 150, 20, 4), ("musigmaaismppi", 256, 20, 3), ("pmcmppi", 128, 15, 3), ("gmppi", 256, 25, 1)])
+def test_level3_run_trials_car(eng_mod, oracle, track, kind, K, T, N):
+    """Device-resident closed loop (simulate_car_racing trial loop) vs the oracle's run_trial: same Philox
+    streams, so per-step actions and the per-trial records must agree."""
+    B, steps, seed = 3, 30, 20240000
+    eng = eng_mod.Engine("car", 1, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track, seed=seed)
+    rec, acts = eng.run_trials(num_steps=steps, laps=2, log_actions=True)
+    for b in range(B):
+        env, pol = make_oracle(oracle, track, kind, 1, K, T, N=N)
+        r = pol.run_trial(env, seed + b + 1, num_steps=steps, laps=2, log_actions=True)
+        assert r["status"] == 0 and rec[b, 15] == 0
+        assert rec[b, 1] == r["steps"] and rec[b, 14] == r["rollouts"]
+        assert np.max(np.abs(acts[b] - r["actions"])) < 1e-6, np.max(np.abs(acts[b] - r["actions"]))
+        ref = [r["rew"], r["steps"], r["rew_per_step"]] + r["lap_t"] + [r["mean_v"], r["max_v"], r["mean_beta"], r["max_beta"],
+                                                                     r["beta_viol"], r["trk_viol"], r["crash_viol"]]
+        assert rel_err(rec[b, :14], ref) < 1e-6, (rec[b, :14], ref)
+    x, _, _ = eng.get_state()
+    assert np.all(np.isfinite(x))
+    eng.close()
+
+
+def test_level3_run_trials_mountaincar(eng_mod, oracle):
+    K, T = 20, 15
+    eng = eng_mod.Engine("mountaincar", 0, "mppi", K, T, batch=2, lam=0.1, cov=[1.5], seed=5)
+    eng.set_state(np.array([[-0.5, 0.0], [-0.45, 0.0]]))
+    rec = eng.run_trials(num_steps=200, laps=0)
+    for b, x0 in enumerate([-0.5, -0.45]):
+        env = oracle.OracleEnv("mountaincar"); env.state = [x0, 0.0]
+        pol = oracle.OraclePolicy("mppi", env, K, T, lam=0.1, U0=[0.0], cov=[1.5])
+        r = pol.run_trial(env, 5 + b + 1, num_steps=200)
+        assert rec[b, 1] == r["steps"], (rec[b], r)
+        assert abs(rec[b, 0] - r["rew"]) < 1e-6 * abs(r["rew"])
+    eng.close()
