@@ -137,6 +137,12 @@ int  mpopis_policy_step(mpopis_handle *h, const mpopis_noise *noise,
  * multi-car_racing.jl:200-207,145-158; mountaincar_example.jl:4-22.  action B*as, reward B out. */
 int  mpopis_env_step(mpopis_handle *h, const double *action, double *reward);
 
+/* reward(env), within_track(env), calculate_β(env) for the resident envs WITHOUT stepping
+ * (src/envs/car_racing.jl:178-213; car_racing_tracks.jl:68-92; multi-car_racing.jl:122-158).
+ * reward B; within B (car: all cars inside the lane, multi-car :122-128; MountainCar: 1);
+ * dist / beta: B x num_cars (distance to the centre line, atan(Vy,Vx)); any pointer may be NULL. */
+int  mpopis_env_query(mpopis_handle *h, double *reward, int32_t *within, double *dist, double *beta);
+
 /* pol.logger.trajectories (src/mppi_mpopi_policies.jl:92-95, src/utils.jl:139-141): B x K x (H x ss),
  * state after each model step of the LAST simulate_model call; needs cfg.log_trajectories. */
 int  mpopis_get_trajectories(mpopis_handle *h, double *out);

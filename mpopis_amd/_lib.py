@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "mpopis_set_env_params", "mpopis_set_track", "mpopis_set_action_bounds", "mpopis_reset",
     "mpopis_set_state", "mpopis_get_state", "mpopis_set_U", "mpopis_get_U", "mpopis_set_Sigma",
     "mpopis_seed", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
-    "mpopis_get_trajectories", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
+    "mpopis_env_query", "mpopis_get_trajectories", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
 ]
 
@@ -79,6 +79,7 @@ def lib():
         L.mpopis_rollout_costs.argtypes = [H, _dp, _dp, _dp, _dp, _dp, _dp]
         L.mpopis_policy_step.argtypes = [H, C.POINTER(Noise), _dp, _dp, _dp, _dp, _ip, _ip]
         L.mpopis_env_step.argtypes = [H, _dp, _dp]
+        L.mpopis_env_query.argtypes = [H, _dp, _ip, _dp, _dp]
         L.mpopis_get_trajectories.argtypes = [H, _dp]
         L.mpopis_run_trials.argtypes = [H, C.c_int32, C.c_int32, _dp, _dp]
         L.mpopis_timing_enable.argtypes = [H, C.c_int32]

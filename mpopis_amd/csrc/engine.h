@@ -75,6 +75,8 @@ void launch_transpose_out(const double* src_rows, const double* shiftA, const do
 void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action,
                      double* reward, int* status, const int* alive, int B, hipStream_t s);
 
+void launch_env_query(const EnvDesc& env, const double* x, const int* done, double* reward, int* within, double* dist, double* beta, int B, hipStream_t s);
+
 // kernels_sample.hip
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
                           uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s);

@@ -341,6 +341,21 @@ int mpopis_env_step(mpopis_handle* h, const double* action, double* reward) {
     return sync_status(h);
 }
 
+int mpopis_env_query(mpopis_handle* h, double* reward, int32_t* within, double* dist, double* beta) {
+    if (!h) return MPOPIS_ERR_ARG;
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, NC = std::max(1, h->env.ncars);
+    if (!h->d_qdist) { if (dalloc(h, &h->d_qdist, (size_t)B * NC) || dalloc(h, &h->d_qbeta, (size_t)B * NC) || dalloc(h, &h->d_qwithin, B)) return MPOPIS_ERR_HIP; }
+    launch_env_query(h->env, h->d_x, h->d_done, h->d_reward, h->d_qwithin, h->d_qdist, h->d_qbeta, B, h->stream);
+    if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
+    if (within) HIPCHK(h, hipMemcpyAsync(within, h->d_qwithin, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    if (dist) HIPCHK(h, hipMemcpyAsync(dist, h->d_qdist, sizeof(double) * B * NC, hipMemcpyDeviceToHost, h->stream));
+    if (beta) HIPCHK(h, hipMemcpyAsync(beta, h->d_qbeta, sizeof(double) * B * NC, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MPOPIS_OK;
+}
+
 int mpopis_get_trajectories(mpopis_handle* h, double* out) {
     if (!h || !out) return MPOPIS_ERR_ARG;
     if (!h->d_traj) { h->err = "log_trajectories was not enabled"; return MPOPIS_ERR_ARG; }

@@ -190,6 +190,40 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
         }
     }
 }
+// reward(env) / within_track / β of the resident state, no step
+__global__ void __launch_bounds__(64) k_env_query(EnvDesc env, const double* x, const int* done, double* reward, int* within, double* dist, double* beta) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
+        if (reward) reward[b] = mc_reward(env.mc, x + (size_t)b * 2, done[b]);
+        if (within) within[b] = 1;
+        return;
+    }
+    const int NC = env.ncars;
+    const double* xb = x + (size_t)b * 8 * NC;
+    double rew = 0.0; int win = 1;
+    for (int i = 0; i < NC; ++i) {
+        const double* s = xb + 8 * i;
+        double d;
+        const bool w = within_track(env.track, s[0], s[1], &d);
+        if (!w) win = 0;
+        if (dist) dist[(size_t)b * NC + i] = d;
+        if (beta) beta[(size_t)b * NC + i] = atan2(s[4], s[3]);
+        rew += car_reward(env.car, env.track, s[0], s[1], s[3], s[4]);
+        for (int j = i + 1; j < NC; ++j) {
+            const double dx = xb[8 * j] - s[0], dy = xb[8 * j + 1] - s[1];
+            const double dd = sqrt(dx * dx + dy * dy);
+            rew += -dd;
+            if (dd <= 4.0) rew += -11000.0;
+        }
+    }
+    if (reward) reward[b] = rew;
+    if (within) within[b] = win;
+}
+void launch_env_query(const EnvDesc& env, const double* x, const int* done, double* reward, int* within, double* dist, double* beta, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_env_query, dim3(B), dim3(64), 0, s, env, x, done, reward, within, dist, beta);
+}
+
 void launch_env_step(const EnvDesc& env, double* x, int* t, int* done, const double* action, double* reward, int* status, const int* alive, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_env_step, dim3(B), dim3(64), 0, s, env, x, t, done, action, reward, status, alive);
 }

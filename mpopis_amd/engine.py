@@ -186,6 +186,16 @@ class Engine:
         check(self._h, self.L.mpopis_env_step(self._h, _d(a), _d(rew)))
         return rew
 
+    def env_query(self):
+        """(reward, within, dist, beta) of the resident envs without stepping."""
+        nc = max(1, self.as_ // 2) if self.env_kind == "car" else 1
+        rew = np.zeros(self.B)
+        within = np.zeros(self.B, dtype=np.int32)
+        dist = np.zeros((self.B, nc))
+        beta = np.zeros((self.B, nc))
+        check(self._h, self.L.mpopis_env_query(self._h, _d(rew), _i(within), _d(dist), _d(beta)))
+        return rew, within.astype(bool), dist, beta
+
     def get_trajectories(self):
         out = np.zeros((self.B, self.K, self.ss, self.T))       # per sample: Julia (T x ss) column-major
         check(self._h, self.L.mpopis_get_trajectories(self._h, _d(out)))

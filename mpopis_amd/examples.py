@@ -1,0 +1,151 @@
+"""simulate_car_racing / simulate_mountaincar (src/examples/car_example.jl:51-416,
+mountaincar_example.jl:49-207): the trial loop runs as ONE device-resident batch (all trials are
+independent, car_example.jl:170), optionally sharded over ranks with one RCCL gather of the per-trial
+summary records (torch.distributed, backend nccl == RCCL).  Prints the reference's tables."""
+import math
+import time
+import numpy as np
+
+from .engine import Engine
+from ._lib import MPOPISError, ERR_ARG, RECORD_LEN
+
+
+def quantile_ci(x, p=0.05, q=0.5):
+    """src/examples/example_utils.jl:2-10 (order-statistic CI of the median, normal approximation)."""
+    x = np.sort(np.asarray(x, dtype=np.float64))
+    n = len(x)
+    zm, zp = -1.959963984540054, 1.959963984540054          # quantile(Normal(), p/2), p = 0.05
+    if p != 0.05:
+        from statistics import NormalDist
+        zm, zp = NormalDist().inv_cdf(p / 2), NormalDist().inv_cdf(1 - p / 2)
+    j = max(int(math.ceil(n * q + zm * math.sqrt(n * q * (1 - q)))), 1)
+    k = min(int(math.ceil(n * q + zp * math.sqrt(n * q * (1 - q)))), n)
+    return x[j - 1], float(np.quantile(x, q)), x[k - 1]
+
+
+def _summary(rows):
+    """AVE/STD/MED/L95/U95/MIN/MAX per column (car_example.jl:328-410)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    out = {}
+    out["AVE"] = rows.mean(0)
+    out["STD"] = rows.std(0, ddof=1) if rows.shape[0] > 1 else np.full(rows.shape[1], np.nan)
+    q = np.array([quantile_ci(rows[:, c]) for c in range(rows.shape[1])])
+    out["MED"], out["L95"], out["U95"] = q[:, 1], q[:, 0], q[:, 2]
+    out["MIN"], out["MAX"] = rows.min(0), rows.max(0)
+    return out
+
+
+def _gather_records(rec, dist):
+    """One collective for summary stats only: RCCL gather to rank 0."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return rec
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    # ranks may hold different numbers of trials: pad to the maximum (row id 0 marks padding)
+    n = torch.tensor([rec.shape[0]], device=dev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    nmax, width = int(n.item()), rec.shape[1]
+    pad = np.zeros((nmax, width))
+    pad[:rec.shape[0]] = rec
+    t = torch.from_numpy(pad).to(dev)
+    gl = [torch.zeros_like(t) for _ in range(dist.get_world_size())] if dist.get_rank() == 0 else None
+    dist.gather(t, gl, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    out = np.concatenate([g.cpu().numpy() for g in gl], axis=0)
+    return out[out[:, 0] > 0]
+
+
+def shard_trials(num_trials, rank, world):
+    """trial k (1-based) -> rank (k-1) mod world; returns this rank's 1-based trial ids."""
+    return [k for k in range(1, num_trials + 1) if (k - 1) % world == rank]
+
+
+def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="cemppi", laps=2, num_samples=150, horizon=50,
+                        λ=10.0, α=1.0, U0=None, cov_mat=None, ais_its=10, λ_ais=20.0, ce_elite_threshold=0.8, ce_Σ_est="mle",
+                        cma_σ=0.75, cma_elite_threshold=0.8, seed=None, log_runs=True, device=0, dist=None, quiet=False):
+    """Returns (records, summary) on rank 0 (None elsewhere).  Differences from the reference harness, all
+    forced by the platform: plotting/GIF options are not offered (out of scope), state noise σ is 0, and
+    ce_Σ_est defaults to :mle (the reference default :ss is a third-party estimator not on the device yet)."""
+    pt = str(policy_type).lstrip(":")
+    rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+    world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
+    if seed is None:
+        seed = int(np.random.default_rng().integers(1, 10 ** 10))
+    U0 = np.zeros(num_cars * 2) if U0 is None else np.asarray(U0, dtype=np.float64)
+    cov_mat = np.tile([0.0625, 0.1], num_cars) if cov_mat is None else cov_mat
+    mine = shard_trials(num_trials, rank, world)
+    rec = np.zeros((0, RECORD_LEN + 2))
+    t0 = time.time()
+    if mine:
+        # slots of one handle use consecutive seeds seed+b+1: give every trial id its own handle seed offset
+        groups = []                      # consecutive runs of trial ids with stride `world`
+        rows = []
+        for k in mine:
+            groups.append(k)
+        # trial ids on this rank are k0, k0+world, ...: run them as separate 1-slot seeds inside one batch when world==1
+        if world == 1:
+            eng = Engine("car", num_cars, pt, num_samples, horizon, batch=len(mine), lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
+                         elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
+                         cma_sigma=cma_σ, seed=seed, device=device, cov=cov_mat, U0=U0)
+            r = eng.run_trials(num_steps, laps)
+            eng.close()
+            rows = [np.concatenate([[k], r[i], [0.0]]) for i, k in enumerate(mine)]
+        else:
+            for k in mine:
+                eng = Engine("car", num_cars, pt, num_samples, horizon, batch=1, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
+                             elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
+                             cma_sigma=cma_σ, seed=seed + k - 1, device=device, cov=cov_mat, U0=U0)
+                r = eng.run_trials(num_steps, laps)
+                eng.close()
+                rows.append(np.concatenate([[k], r[0], [0.0]]))
+        rec = np.array(rows)
+        rec[:, -1] = time.time() - t0          # Ex Time of this rank's batch (trials run concurrently)
+    allrec = _gather_records(rec, dist)
+    if allrec is None:
+        return None, None
+    allrec = allrec[np.argsort(allrec[:, 0])]
+    cols = [1, 2, 3] + [4 + i for i in range(laps)] + [8, 9, 10, 11, 12, 13] + ([14] if num_cars > 1 else []) + [allrec.shape[1] - 1]
+    table = allrec[:, cols]
+    summ = _summary(table)
+    if log_runs and not quiet:
+        hdr = "Trial    #: %12s : %7s: %12s" % ("Reward", "Steps", "Reward/Step")
+        hdr += "".join(" : %6s%d" % ("lap ", i + 1) for i in range(laps))
+        hdr += " : %7s : %7s : %7s : %7s : %7s : %7s" % ("Mean V", "Max V", "Mean β", "Max β", "β Viol", "T Viol")
+        hdr += (" : %7s" % "C Viol" if num_cars > 1 else "") + " : %7s" % "Ex Time"
+        print(hdr)
+        for row, full in zip(table, allrec):
+            print("Trial %4d: " % int(full[0]) + " : ".join("%12.2f" % v if i in (0, 2) else "%7.2f" % v for i, v in enumerate(row)))
+        print("-----------------------------------")
+        for name in ("AVE", "STD", "MED", "L95", "U95", "MIN", "MAX"):
+            print("Trials %3s: " % name + " : ".join("%12.2f" % v if i in (0, 2) else "%7.2f" % v for i, v in enumerate(summ[name])))
+    return allrec, summ
+
+
+def simulate_mountaincar(num_trials=1, num_steps=200, policy_type="cemppi", num_samples=20, horizon=15, λ=0.1, α=1.0, U0=(0.0,),
+                         cov_mat=(1.5,), ais_its=5, λ_ais=0.1, ce_elite_threshold=0.8, ce_Σ_est="mle", cma_σ=0.75,
+                         cma_elite_threshold=0.8, seed=None, x0=None, log_runs=True, device=0, quiet=False):
+    """mountaincar_example.jl:49-207; x0: per-trial start positions (the reference draws them unseeded)."""
+    pt = str(policy_type).lstrip(":")
+    if seed is None:
+        seed = int(np.random.default_rng().integers(1, 10 ** 10))
+    eng = Engine("mountaincar", 0, pt, num_samples, horizon, batch=num_trials, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
+                 elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
+                 cma_sigma=cma_σ, seed=seed, device=device, cov=np.asarray(cov_mat, dtype=np.float64), U0=np.asarray(U0, dtype=np.float64))
+    if x0 is not None:
+        x0 = np.asarray(x0, dtype=np.float64).reshape(num_trials)
+        eng.set_state(np.stack([x0, np.zeros(num_trials)], 1))
+    t0 = time.time()
+    rec = eng.run_trials(num_steps, 0)
+    ex = time.time() - t0
+    eng.close()
+    table = np.concatenate([rec[:, :3], np.full((num_trials, 1), ex)], 1)
+    summ = _summary(table)
+    if log_runs and not quiet:
+        print("Trial    #: %12s : %7s: %12s : %7s" % ("Reward", "Steps", "Reward/Step", "Ex Time"))
+        for k, row in enumerate(table):
+            print("Trial %4d: %12.2f : %7d: %12.2f : %7.2f" % (k + 1, row[0], int(row[1]), row[2], row[3]))
+        print("-----------------------------------")
+        for name in ("AVE", "STD", "MED", "L95", "U95", "MIN", "MAX"):
+            print("Trials %3s: %12.2f : %7.2f: %12.2f : %7.2f" % ((name,) + tuple(summ[name])))
+    return rec, summ

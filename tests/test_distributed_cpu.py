@@ -1,0 +1,46 @@
+"""N>1 path on CPU: trial sharding + the single summary-stats gather, world_size 2 over gloo."""
+import os
+import socket
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mpopis_amd.examples import shard_trials, _gather_records
+    mine = shard_trials(7, rank, world)
+    rec = np.array([[k] + [float(k * 10 + i) for i in range(5)] for k in mine])
+    out = _gather_records(rec, dist)
+    if rank == 0:
+        q.put(out[np.argsort(out[:, 0])])
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    from mpopis_amd.examples import shard_trials
+    assert shard_trials(7, 0, 2) == [1, 3, 5, 7] and shard_trials(7, 1, 2) == [2, 4, 6]
+    assert sorted(sum((shard_trials(64, r, 8) for r in range(8)), [])) == list(range(1, 65))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # rank 0 holds 4 trials, rank 1 holds 3: uneven shards are padded inside _gather_records
+    assert list(out[:, 0]) == [1, 2, 3, 4, 5, 6, 7]
+    assert np.array_equal(out[:, 1], np.arange(1, 8) * 10.0)

@@ -1,0 +1,97 @@
+"""The Python host mirror of the reference's operator API, exercised the way the reference's own
+callers use it (src/examples/car_example.jl:170-281): env + get_policy + pol(env) + env(act) + reward."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def M():
+    from mpopis_amd import build
+    build.build()
+    import mpopis_amd
+    return mpopis_amd
+
+
+def test_closed_loop_like_reference_harness(M, oracle, track):
+    rng = np.random.default_rng(21)
+    K, T, N = 150, 20, 4
+    env = M.CarRacingEnv()
+    pol = M.get_policy(":cemppi", env, K, T, 10.0, 1.0, np.zeros(2), np.array([0.0625, 0.1]), False, N, 20.0, 0.8, "mle", 0.75, 0.8)
+    oenv = oracle.OracleEnv("car", 1, track=track)
+    opol = oracle.OraclePolicy("cemppi", oenv, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, elite_threshold=0.8)
+    assert np.allclose(env.state, oenv.state)
+    rew = 0.0
+    for cnt in range(6):
+        Z = rng.standard_normal((N, K, 2 * T))
+        act = pol(env, Z=Z)                       # act = pol(env)
+        ref = opol(oenv, Z)
+        assert np.max(np.abs(act - ref["control"])) < 1e-8
+        env(act)                                  # env(act)
+        oenv.step(ref["control"])
+        assert np.max(np.abs(env.state - oenv.state)) < 1e-8
+        r = M.reward(env)
+        assert abs(r - oenv.reward()) < 1e-8 * abs(oenv.reward())
+        rew += r
+        w, d = M.within_track(env)
+        ow, od = oracle.within_track(track, oenv.state[:2])
+        assert w == ow and abs(d - od) < 1e-9
+        assert not M.exceed_β(env)
+    assert np.max(np.abs(pol.U - opol.U)) < 1e-8
+    pol.close()
+
+
+def test_policy_constructors_and_errors(M):
+    env = M.MultiCarRacingEnv(3)
+    assert list(env.state[[0, 8, 16]]) == [0.0, 5.0, -5.0]
+    lo, hi = M.action_space(env)
+    assert len(lo) == 6 and np.all(lo == -1) and np.all(hi == 1)
+    pol = M.CMAMPPI_Policy(env, num_samples=256, horizon=10, λ=10.0, U0=np.zeros(6), cov_mat=M.block_diagm([0.0625, 0.1], 3), opt_its=3, σ=0.75)
+    assert pol.Σ.shape == (60, 60) and pol.params.cs == 60
+    a = pol(env)
+    assert a.shape == (6,) and np.all(np.abs(a) <= 1.0)
+    env(a)
+    assert env.t == 1 and np.isfinite(M.reward(env))
+    pol.close()
+    with pytest.raises(M.MPOPISError):
+        M.GMPPI_Policy(env, num_samples=8, horizon=4, U0=np.zeros(5))          # "U₀ must be length of action space or control space"
+    with pytest.raises(M.MPOPISError):
+        M.get_policy(":nope", env, 8, 4, 1.0, 1.0, np.zeros(6), np.ones(6), False, 2, 1.0, 0.8, "mle", 1.0, 0.8)
+    with pytest.raises(M.MPOPISError):
+        M.CEMPPI_Policy(env, Σ_est="bogus")
+    e1 = M.CarRacingEnv()
+    with pytest.raises(M.MPOPISError):
+        e1([2.0, 0.0])                                                          # Action is not in action space
+
+
+def test_logger_and_calculate_trajectory_costs(M, oracle, track):
+    env = M.CarRacingEnv()
+    pol = M.GMPPI_Policy(env, num_samples=64, horizon=8, λ=10.0, U0=np.zeros(2), cov_mat=[0.0625, 0.1], log=True)
+    rng = np.random.default_rng(5)
+    Z = rng.standard_normal((1, 64, 16))
+    cost, E, w = M.calculate_trajectory_costs(pol, env, Z=Z)
+    assert E.shape == (16, 64) and abs(w.sum() - 1) < 1e-12
+    assert len(pol.logger.trajectories) == 64 and pol.logger.trajectories[0].shape == (8, 8)
+    oenv = oracle.OracleEnv("car", 1, track=track)
+    opol = oracle.OraclePolicy("gmppi", oenv, 64, 8, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1])
+    c2, tr = opol.simulate_model(np.zeros(16), E, log=True)
+    assert np.max(np.abs(cost - c2) / np.abs(c2)) < 1e-8
+    assert np.max(np.abs(np.array(pol.logger.trajectories) - tr)) < 1e-8
+    pol.U = np.zeros(16)
+    c3 = M.simulate_model(pol, env, E)
+    assert np.max(np.abs(c3 - c2) / np.abs(c2)) < 1e-8
+    pol.close()
+
+
+def test_simulate_car_racing_and_mountaincar(M):
+    rec, summ = M.simulate_car_racing(num_trials=4, num_steps=20, policy_type=":μΣaismppi", num_samples=256, horizon=20, ais_its=3,
+                                      seed=123, quiet=True)
+    assert rec.shape[0] == 4 and np.all(rec[:, 2] == 20) and np.all(rec[:, 13] == 0)     # steps, no track violations
+    assert np.all(rec[:, 8] > 9.0)                                                       # mean speed
+    assert summ["AVE"].shape == summ["MAX"].shape
+    rec2, _ = M.simulate_car_racing(num_trials=4, num_steps=20, policy_type=":μΣaismppi", num_samples=256, horizon=20, ais_its=3,
+                                    seed=123, quiet=True)
+    assert np.array_equal(rec[:, :15], rec2[:, :15])                                    # deterministic for a fixed seed
+    recm, _ = M.simulate_mountaincar(num_trials=3, num_steps=200, policy_type=":mppi", x0=[-0.5, -0.45, -0.55], seed=9, quiet=True)
+    assert recm.shape == (3, 16) and np.all(recm[:, 1] >= 1)
