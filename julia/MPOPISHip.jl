@@ -1,0 +1,136 @@
+# MPOPISHip.jl -- the reference-side binding for libmpopis_hip.so (include/mpopis.h).
+#
+# SOURCE ONLY: Julia is not installed in the build image, so this file has never been executed
+# there; it is the thin `ccall` layer a MPOPIS maintainer adds.  It plugs in exactly where the
+# reference already dispatches on the env type for its EnvPool backend
+# (src/mppi_mpopi_policies.jl:148 vs :186, :240 vs :261): more specific methods of
+#     (pol::AbstractPathIntegralPolicy)(env)         -> mpopis_policy_step
+#     simulate_model(pol, env, E, Σ_inv, U_orig)     -> mpopis_rollout_costs
+# for env::CarRacingEnv / MultiCarRacingEnv / MountainCarEnv.  Every other env type keeps falling
+# through to the Julia CPU methods unchanged.  Policy symbols, constructors, `get_policy`,
+# `seed!`, `pol.U`, `pol.Σ`, `pol.logger` are untouched.
+module MPOPISHip
+
+using MPOPIS
+using MPOPIS: AbstractPathIntegralPolicy, AbstractGMPPI_Policy, MPPI_Policy, GMPPI_Policy, IMPPI_Policy,
+              CEMPPI_Policy, CMAMPPI_Policy, μAISMPPI_Policy, μΣAISMPPI_Policy, PMCMPPI_Policy,
+              CarRacingEnv, MultiCarRacingEnv
+using ReinforcementLearning: MountainCarEnv
+import MPOPIS: simulate_model
+
+const LIB = get(ENV, "MPOPIS_HIP_LIB", joinpath(@__DIR__, "..", "mpopis_amd", "lib", "libmpopis_hip.so"))
+
+# mirrors `mpopis_config` (include/mpopis.h) field for field
+struct Config
+    device::Int32; env_kind::Int32; num_cars::Int32; policy::Int32
+    num_samples::Int32; horizon::Int32; batch::Int32; ais_its::Int32
+    sigma_est::Int32; log_trajectories::Int32
+    lambda::Float64; alpha::Float64; lambda_ais::Float64; elite_threshold::Float64; cma_sigma::Float64
+    seed::UInt64
+end
+
+policy_id(::MPPI_Policy) = 0;  policy_id(::GMPPI_Policy) = 1;  policy_id(::IMPPI_Policy) = 2
+policy_id(::CEMPPI_Policy) = 3; policy_id(::CMAMPPI_Policy) = 4; policy_id(::μAISMPPI_Policy) = 5
+policy_id(::μΣAISMPPI_Policy) = 6; policy_id(::PMCMPPI_Policy) = 7
+
+env_kind(::MountainCarEnv) = (0, 0)
+env_kind(::CarRacingEnv) = (1, 1)
+env_kind(env::MultiCarRacingEnv) = (1, env.N)
+
+ais_its(pol) = hasproperty(pol, :opt_its) ? pol.opt_its : 1
+lam_ais(pol) = hasproperty(pol, :λ_ais) ? pol.λ_ais : 0.0
+elite(pol::CEMPPI_Policy) = pol.ce_elite_threshold
+elite(pol::CMAMPPI_Policy) = 1.0 - pol.m_elite / pol.params.num_samples
+elite(pol) = 0.8
+cma_sigma(pol::CMAMPPI_Policy) = pol.σ
+cma_sigma(pol) = 1.0
+
+car_param_vector(env::CarRacingEnv) = Float64[getfield(env.params, f) for f in fieldnames(typeof(env.params))] |>
+                                      v -> vcat(v, env.dt, env.δt)
+car_param_vector(env::MultiCarRacingEnv) = car_param_vector(env.envs[1])
+track_of(env::CarRacingEnv) = env.track
+track_of(env::MultiCarRacingEnv) = env.envs[1].track
+
+check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:mpopis_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
+
+const HANDLES = IdDict{Any,Ptr{Cvoid}}()       # one engine handle per policy object
+
+function handle(pol, env)
+    get!(HANDLES, pol) do
+        kind, ncars = env_kind(env)
+        cfg = Config(0, kind, ncars, policy_id(pol), pol.params.num_samples, pol.params.horizon, 1, ais_its(pol),
+                     0, pol.params.log, pol.params.λ, pol.params.α, lam_ais(pol), elite(pol), cma_sigma(pol), rand(UInt64))
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:mpopis_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out)
+        rc == 0 || error(unsafe_string(ccall((:mpopis_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+        h = out[]
+        if kind == 1
+            p = car_param_vector(env); tr = track_of(env)
+            check(h, ccall((:mpopis_set_env_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), h, p, length(p)))
+            check(h, ccall((:mpopis_set_track, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
+                           h, tr.x′, tr.y′, tr.lane_width′, length(tr.x′)))
+        else
+            pr = env.params
+            p = Float64[pr.min_pos, pr.max_pos, pr.max_speed, pr.goal_pos, pr.goal_velocity, pr.power, pr.gravity, pr.max_steps]
+            check(h, ccall((:mpopis_set_env_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), h, p, length(p)))
+        end
+        Σ = Matrix{Float64}(pol.Σ)                       # column-major, as×as (:mppi) or cs×cs
+        check(h, ccall((:mpopis_set_Sigma, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), h, Σ, size(Σ, 1)))
+        finalizer(_ -> ccall((:mpopis_destroy, LIB), Cvoid, (Ptr{Cvoid},), h), pol)
+        h
+    end
+end
+
+env_t(env) = hasproperty(env, :t) ? Int32(env.t) : Int32(0)
+
+# ---- control = pol(env) ------------------------------------------------------------------------------
+function hip_policy_call(pol::AbstractPathIntegralPolicy, env)
+    h = handle(pol, env)
+    K, as = pol.params.num_samples, pol.params.as
+    x = Vector{Float64}(MPOPIS.state(env)); t = Int32[env_t(env)]; done = Int32[env.done]
+    control = Vector{Float64}(undef, as); cost = Vector{Float64}(undef, K); w = Vector{Float64}(undef, K)
+    GC.@preserve x t done control cost w begin
+        check(h, ccall((:mpopis_set_state, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}), h, x, t, done))
+        check(h, ccall((:mpopis_set_U, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, pol.U))
+        check(h, ccall((:mpopis_policy_step, LIB), Cint,
+                       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+                       h, C_NULL, control, cost, w, C_NULL, C_NULL, C_NULL))
+        check(h, ccall((:mpopis_get_U, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, pol.U))   # rolled in place (same array as params.U₀)
+    end
+    if pol.params.log
+        pol.logger.traj_costs = cost; pol.logger.traj_weights = w
+    end
+    return as == 1 ? control : reshape(control, as, 1)        # get_model_controls returns as×1 (utils.jl:55-67)
+end
+
+for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv)
+    @eval (pol::MPPI_Policy)(env::$E) = hip_policy_call(pol, env)
+    @eval (pol::AbstractGMPPI_Policy)(env::$E) = hip_policy_call(pol, env)
+end
+
+# ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) ----------------------------------------
+function hip_simulate_model(pol::AbstractGMPPI_Policy, env, E::Matrix{Float64}, Σ_inv::Matrix{Float64}, U_orig::Vector{Float64})
+    h = handle(pol, env)
+    cost = Vector{Float64}(undef, pol.params.num_samples)
+    x = Vector{Float64}(MPOPIS.state(env))
+    γ = pol.params.λ * (1 - pol.params.α)
+    GC.@preserve x E Σ_inv U_orig cost begin
+        check(h, ccall((:mpopis_rollout_costs, LIB), Cint,
+                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                       h, x, pol.U, U_orig, E, γ == 0 ? C_NULL : pointer(Σ_inv), cost))
+    end
+    return cost
+end
+for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv)
+    @eval simulate_model(pol::AbstractGMPPI_Policy, env::$E, E::Matrix{Float64}, Σ_inv::Matrix{Float64}, U_orig::Vector{Float64}) =
+        hip_simulate_model(pol, env, E, Σ_inv, U_orig)
+end
+
+# Random.seed!(pol, seed) also reseeds the device streams
+function MPOPIS.seed!(pol::AbstractPathIntegralPolicy, seed::Integer)
+    MPOPIS.Random.seed!(pol.rng, seed)
+    haskey(HANDLES, pol) && check(HANDLES[pol], ccall((:mpopis_seed, LIB), Cint, (Ptr{Cvoid}, UInt64), HANDLES[pol], UInt64(seed - 1)))
+    pol
+end
+
+end # module
