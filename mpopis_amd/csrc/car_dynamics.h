@@ -45,7 +45,7 @@ struct CarParams {
     // derived on the host once
     int nsub;            // round(Int, dt/δt) :299
     int blim_acute;      // β_limit < pi/2
-    double inv_m, inv_Izz, L, tan_blim;
+    double inv_m, inv_Izz, L, tan_blim, inv_dt, inv_L, fz0f, fz0r;
 };
 
 MP_HD CarParams make_car_params(const double* p) {
@@ -56,13 +56,15 @@ MP_HD CarParams make_car_params(const double* p) {
     c.dt = p[18]; c.ddt = p[19];
     c.nsub = (int)nearbyint(c.dt / c.ddt);
     c.inv_m = 1 / c.m; c.inv_Izz = 1 / c.Izz; c.L = c.lr + c.lf;
+    c.inv_dt = 1 / c.dt; c.inv_L = 1 / c.L;
+    c.fz0f = c.m * c.lr * 9.81; c.fz0r = c.m * c.lf * 9.81;                    // :262-272
     c.blim_acute = c.blim < 0.5 * kPi;
     c.tan_blim = c.blim_acute ? tan(c.blim) : tan(kPi - c.blim);
     return c;
 }
 
-struct Track {           // env.track.{x′,y′,lane_width′}
-    const double* x; const double* y; const double* w; int P;
+struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[i]^2 + y′[i]^2, derived)
+    const double* x; const double* y; const double* w; const double* n2; int P;
 };
 
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
@@ -106,9 +108,10 @@ struct TireK { double fymax, thr, k2, k3; };
 MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
     TireK k;
     k.fymax = sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));           // :253
-    k.thr = 3 * k.fymax / Ca;                                  // tan of the switch angle :255
-    k.k2 = (Ca * Ca) / (3 * k.fymax);
-    k.k3 = (Ca * Ca * Ca) / (27 * (k.fymax * k.fymax));
+    const double rf = fast_rcp(k.fymax), rc = 1.0 / Ca;        // rc: Ca is wave-uniform
+    k.thr = 3 * k.fymax * rc;                                  // tan of the switch angle :255
+    k.k2 = ((Ca * Ca) * (1.0 / 3.0)) * rf;                     // C^2/(3 fy_max)
+    k.k3 = ((Ca * Ca * Ca) * (1.0 / 27.0)) * (rf * rf);        // C^3/(27 fy_max^2)
     return k;
 }
 
@@ -125,87 +128,118 @@ MP_HD void car_state_to8(const CarState& c, double* s) {
     s[0] = c.x; s[1] = c.y; s[2] = c.psi; s[3] = c.Vx; s[4] = c.Vy; s[5] = c.r; s[6] = c.delta; s[7] = c.pedal;
 }
 
-// env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
-// Transcendental-free for every sign of Vx (requires |delta| < pi/2, guaranteed by delta_max and
-// actions in [-1,1]):
+// sin/cos for |v| <= 1/16 (truncation < 3e-20 relative): the per-sub-step yaw increment
+MP_HD void sincos_tiny(double v, double* s, double* c) {
+    const double v2 = v * v;
+    double ps = 1.0 / 362880.0;
+    ps = fma(ps, v2, -1.0 / 5040.0);
+    ps = fma(ps, v2, 1.0 / 120.0);
+    ps = fma(ps, v2, -1.0 / 6.0);
+    *s = fma(ps * v2, v, v);
+    double pc = 1.0 / 40320.0;
+    pc = fma(pc, v2, -1.0 / 720.0);
+    pc = fma(pc, v2, 1.0 / 24.0);
+    pc = fma(pc, v2, -0.5);
+    *c = fma(pc, v2, 1.0);
+}
+
+// brush tyre, linear branch, Horner form of  -C ta + k2 |ta| ta - k3 ta^3  (:256)
+MP_HD double tire_poly(double ta, double Ca, const TireK& k) {
+    const double at = fabs(ta);
+    return ta * fma(at, fma(-k.k3, at, k.k2), -Ca);
+}
+
+// One Euler sub-step for ANY sign of Vx (cold path of car_action_step; delta, sd, cd already advanced).
 //   rear : alpha_r = atan2(yr,Vx).  |alpha_r| < atan(T)  <=>  Vx > 0 and |yr/Vx| < T; tan(alpha_r) = yr/Vx;
 //          otherwise saturated with sign(alpha_r) = sign(yr) (atan2(0,0) = 0 gives fy = 0).
 //   front: alpha_f = atan2(yf,Vx) - delta is the angle of q = R(-delta)(Vx,yf) up to a 2pi wrap that can
 //          only occur when |alpha_f| > pi (saturated anyway).  Linear branch <=> q.x > 0 and |q.y/q.x| < T;
 //          saturated sign = sign(q.y) if q.x > 0 else sign(yf) (|alpha_f| >= pi/2 > |delta|).
+MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, double cd,
+                               double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp) {
+    const double sg = jl_sign(Vx);
+    const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0) * sg;        // :310-312
+    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
+    const double fxf = lam * fx, fxr = (1 - lam) * fx;
+    const TireK kf = tire_consts(p.muf, p.Caf, (p.m * p.lr * 9.81 - p.h * fx) / p.L, fxf);
+    const TireK kr = tire_consts(p.mur, p.Car, (p.m * p.lf * 9.81 + p.h * fx) / p.L, fxr);
+    const double fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;                               // :308
+    const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
+    double fyr;
+    if (Vx > 0.0 && fabs(yr / Vx) < kr.thr) fyr = tire_poly(yr / Vx, p.Car, kr);
+    else fyr = (Vx == 0.0 && yr == 0.0) ? 0.0 : ((yr >= 0.0) ? -kr.fymax : kr.fymax);
+    double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));
+    if (Vx == 0.0 && yf == 0.0) { xq = cd; yq = -sd; }         // atan2(0,0) = 0 -> alpha_f = -delta
+    double fyf;
+    if (xq > 0.0 && fabs(yq / xq) < kf.thr) fyf = tire_poly(yq / xq, p.Caf, kf);
+    else fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -kf.fymax : kf.fymax;
+    const double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);
+    const double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;
+    const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;
+    r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;
+    double dpsi = r * p.ddt;
+    psi += dpsi;
+    int nrot = 1;
+    if (fabs(dpsi) > 0.25) {                                   // absurd yaw rates (> 25 rad/s): split the rotation
+        nrot = (int)fmin(ceil(fabs(dpsi) * 4.0), 1024.0);
+        dpsi = dpsi / nrot;
+        psi = fmod(psi, kTwoPi);
+    }
+    if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;
+    double sq, cq;
+    sincos_small(dpsi, &sq, &cq);
+    for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+    x += (Vx * cp - Vy * sp) * p.ddt;
+    y += (Vx * sp + Vy * cp) * p.ddt;
+}
+
+// env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
+// Transcendental-free (requires |delta| < pi/2, guaranteed by delta_max and actions in [-1,1]).
+// Hot path (Vx > 0, front slip in the forward half plane, |psi_dot| <= 6.25 rad/s): branch-free,
+// tyre constants hoisted, one shared reciprocal; everything else goes through car_substep_general.
 MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1) {
     double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r, delta = c.delta;
     double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
-    {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation, error ~1e-32)
+    {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation)
         const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
         sp *= fp; cp *= fp; sd *= fd; cd *= fd;
     }
     const double tgt = a0 * p.dmax - delta;
-    const double rate = fmin(fabs(tgt) / p.dt, p.ddotmax) * jl_sign(tgt);      // :295-296
+    const double rate = fmin(fabs(tgt) * p.inv_dt, p.ddotmax) * jl_sign(tgt);  // :295-296
     const double dd = rate * p.ddt;
     const double pedal = a1;                                                   // :297
-    const double accel = p.Fxmax * fmax(pedal, 0.0);                           // :310
-    const double brk = p.Fxmin * fmin(pedal, 0.0);                             // :311 without sign(Vx)
-    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;                     // :315-316
-    const double fz0f = p.m * p.lr * 9.81, fz0r = p.m * p.lf * 9.81;          // :262-272
-    // forces and brush-model constants are constant over the sub-steps while Vx > 0 -> hoisted
-    double fxf = lam * (accel + brk), fxr = (1 - lam) * (accel + brk);
-    TireK kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * (accel + brk)) / p.L, fxf);
-    TireK kr = tire_consts(p.mur, p.Car, (fz0r + p.h * (accel + brk)) / p.L, fxr);
-    bool hoisted_valid = true;
+    // forces and brush-model constants for sign(Vx) = +1, constant over the sub-steps (:310-318)
+    const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0);
+    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
+    const double fxf = lam * fx, fxr = (1 - lam) * fx;
+    const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
+    const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     double sdd, cdd;
-    sincos_small(dd, &sdd, &cdd);                              // |dd| <= ddotmax*δt = 0.0157
+    sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157
     for (int it = 0; it < p.nsub; ++it) {
         delta += dd;                                                           // :301
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }
-        double fx_aero;
-        if (Vx > 0.0) {
-            if (!hoisted_valid) {                              // came back from Vx <= 0
-                fxf = lam * (accel + brk); fxr = (1 - lam) * (accel + brk);
-                kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * (accel + brk)) / p.L, fxf);
-                kr = tire_consts(p.mur, p.Car, (fz0r + p.h * (accel + brk)) / p.L, fxr);
-                hoisted_valid = true;
-            }
-            fx_aero = fma(p.CD1, Vx, p.CD0);                                   // :308
-        } else {                                               // rare: stopped or sliding backwards
-            const double sg = jl_sign(Vx);
-            const double fx = accel + brk * sg;                                // :310-312
-            fxf = lam * fx; fxr = (1 - lam) * fx;
-            kf = tire_consts(p.muf, p.Caf, (fz0f - p.h * fx) / p.L, fxf);
-            kr = tire_consts(p.mur, p.Car, (fz0r + p.h * fx) / p.L, fxr);
-            hoisted_valid = false;
-            fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;
-        }
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
-        // rear tyre
-        const double tar = yr * fast_rcp(Vx);
-        double fyr;
-        if (Vx > 0.0 && fabs(tar) < kr.thr) fyr = -p.Car * tar + kr.k2 * fabs(tar) * tar - kr.k3 * (tar * tar * tar);
-        else fyr = (Vx == 0.0 && yr == 0.0) ? 0.0 : ((yr >= 0.0) ? -kr.fymax : kr.fymax);
-        // front tyre
-        double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));
-        if (Vx == 0.0 && yf == 0.0) { xq = cd; yq = -sd; }     // atan2(0,0) = 0 -> alpha_f = -delta
-        const double taf = yq * fast_rcp(xq);
-        double fyf;
-        if (xq > 0.0 && fabs(taf) < kf.thr) fyf = -p.Caf * taf + kf.k2 * fabs(taf) * taf - kf.k3 * (taf * taf * taf);
-        else fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -kf.fymax : kf.fymax;
+        const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
+        if (!(Vx > 0.0 && xq > 0.0 && fabs(r) <= 6.25)) {                      // cold: stopped / sliding / spinning / NaN
+            car_substep_general(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
+            continue;
+        }
+        const double rinv = fast_rcp(Vx * xq);
+        const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
+        const double fyr = (fabs(tar) < kr.thr) ? tire_poly(tar, p.Car, kr) : -copysign(kr.fymax, yr);
+        const double fyf = (fabs(taf) < kf.thr) ? tire_poly(taf, p.Caf, kf) : -copysign(kf.fymax, yq);
+        const double fx_aero = fma(p.CD1, Vx, p.CD0);                          // :308
         const double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);          // :322
         const double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;                   // :323
         const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;         // :324
         r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;               // :326-328
-        double dpsi = r * p.ddt;
+        const double dpsi = r * p.ddt;
         psi += dpsi;                                                           // :329
-        if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;      // :330 atan(sin,cos)
-        int nrot = 1;
-        if (fabs(dpsi) > 0.25) {                               // absurd yaw rates (> 25 rad/s): split the rotation
-            nrot = (int)fmin(ceil(fabs(dpsi) * 4.0), 1024.0);
-            dpsi = dpsi / nrot;
-            psi = fmod(psi, kTwoPi);
-            if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;
-        }
+        psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);          // :330 atan(sin,cos)
         double sq, cq;
-        sincos_small(dpsi, &sq, &cq);
-        for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        if (fabs(dpsi) <= 0.0625) sincos_tiny(dpsi, &sq, &cq); else sincos_small(dpsi, &sq, &cq);   // |r| may exceed 6.25 after the update
+        { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
         x += (Vx * cp - Vy * sp) * p.ddt;                                      // :331
         y += (Vx * sp + Vy * cp) * p.ddt;                                      // :332
     }
@@ -215,17 +249,17 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
 
 // within_track(track, pos): car_racing_tracks.jl:68-92.  Track arrays are wave-uniform (scalar loads).
 MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out) {
+    // findmin over |q_i - p|^2 (:71-73) evaluated as |q_i|^2 - 2 q_i.p (+|p|^2, common to all i): 2 FMAs per
+    // point; ties/near-ties (< 1e-10 m^2 apart) may resolve differently from the literal form, which is
+    // harmless: the two candidates then share the projected segment.
     int mi = 0;
-    double best;
-    {
-        const double dx = tk.x[0] - px, dy = tk.y[0] - py;
-        best = dx * dx + dy * dy;
-    }
-#pragma unroll 4
-    for (int i = 1; i < tk.P; ++i) {                                           // findmin: first minimum
-        const double dx = tk.x[i] - px, dy = tk.y[i] - py;
-        const double d = dx * dx + dy * dy;
-        if (d < best) { best = d; mi = i; }
+    const double m2x = -2.0 * px, m2y = -2.0 * py;
+    double best = fma(tk.y[0], m2y, fma(tk.x[0], m2x, tk.n2[0]));
+#pragma unroll 8
+    for (int i = 1; i < tk.P; ++i) {                                           // first minimum
+        const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
+        mi = (d < best) ? i : mi;
+        best = fmin(best, d);
     }
     const int im = (mi == 0) ? tk.P - 1 : mi - 1;                              // mod1 :75-76
     const int ip = (mi == tk.P - 1) ? 0 : mi + 1;

@@ -118,7 +118,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     default_car_params(p); h->env.car = make_car_params(p);
     default_mc_params(p); h->env.mc = make_mc_params(p);
     for (int i = 0; i < kMaxAs; ++i) { h->env.lo[i] = -1.0; h->env.hi[i] = 1.0; }
-    h->env.track = Track{nullptr, nullptr, nullptr, 0};
+    h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0};
     const int B = h->B, K = h->K, cs = h->cs;
     const size_t nn = (size_t)cs * cs;
     int rc = 0;
@@ -193,12 +193,15 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     if (!h || !x || !y || !w || P < 2 || P > 2048) { if (h) h->err = "bad track (need 2 <= P <= 2048 points)"; return MPOPIS_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     double* d = nullptr;
-    if (dalloc(h, &d, (size_t)3 * P)) return MPOPIS_ERR_HIP;
+    if (dalloc(h, &d, (size_t)4 * P)) return MPOPIS_ERR_HIP;
+    std::vector<double> n2(P);
+    for (int i = 0; i < P; ++i) n2[i] = x[i] * x[i] + y[i] * y[i];
+    HIPCHK(h, hipMemcpyAsync(d + 3 * P, n2.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d, x, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + P, y, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + 2 * P, w, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->env.track = Track{d, d + P, d + 2 * P, P};
+    h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P};
     return MPOPIS_OK;
 }
 

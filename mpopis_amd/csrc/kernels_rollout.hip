@@ -37,9 +37,10 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
     const int P = a.env.track.P;
     for (int i = threadIdx.x; i < P; i += 64 * NC) {
         sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
+        sh_trk[3 * P + i] = a.env.track.n2[i];
     }
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, P};
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P};
     CarState s;                                               // wave-uniform start state (+ sin/cos), scalar loads
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
@@ -152,7 +153,7 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(k_rollout_mountaincar, grid, dim3(64), 0, st, a);
         return;
     }
-    const size_t lds = (size_t)3 * a.env.track.P * sizeof(double);
+    const size_t lds = (size_t)4 * a.env.track.P * sizeof(double);
     switch (a.env.ncars) {
         case 1: hipLaunchKernelGGL(k_rollout_car<1>, grid, dim3(64), lds, st, a); break;
         case 2: hipLaunchKernelGGL(k_rollout_car<2>, grid, dim3(128), lds, st, a); break;

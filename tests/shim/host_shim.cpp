@@ -2,7 +2,12 @@
 // the fast-path algebra used by the HIP rollout kernel can be checked against the CPU oracle on a
 // machine without a GPU.  Not part of the product; never loaded by mpopis_amd.
 #include "../../mpopis_amd/csrc/car_dynamics.h"
+#include <vector>
 using namespace mpopis;
+static Track mk(int P, const double* tx, const double* ty, const double* tw, std::vector<double>& n2) {
+    n2.resize(P); for (int i = 0; i < P; ++i) n2[i] = tx[i] * tx[i] + ty[i] * ty[i];
+    return Track{tx, ty, tw, n2.data(), P};
+}
 extern "C" {
 void shim_car_action_step(const double* p20, double* s8, double a0, double a1) {
     CarParams p = make_car_params(p20);
@@ -12,14 +17,14 @@ void shim_car_action_step(const double* p20, double* s8, double a0, double a1) {
 }
 double shim_car_reward(const double* p20, int P, const double* tx, const double* ty, const double* tw, const double* s8) {
     CarParams p = make_car_params(p20);
-    Track tk{tx, ty, tw, P};
+    std::vector<double> n2; Track tk = mk(P, tx, ty, tw, n2);
     return car_reward(p, tk, s8[0], s8[1], s8[3], s8[4]);
 }
 // full single-car rollout: controls as x T (already clamped); returns -sum(reward)
 double shim_car_rollout(const double* p20, int P, const double* tx, const double* ty, const double* tw,
                         double* s8, const double* ctrl, int T) {
     CarParams p = make_car_params(p20);
-    Track tk{tx, ty, tw, P};
+    std::vector<double> n2; Track tk = mk(P, tx, ty, tw, n2);
     double c = 0.0;
     CarState st; car_state_from8(st, s8);          // sin/cos evaluated once, then carried (as in the kernel)
     for (int t = 0; t < T; ++t) { car_action_step(p, st, ctrl[2 * t], ctrl[2 * t + 1]); c -= car_reward(p, tk, st.x, st.y, st.Vx, st.Vy); }
