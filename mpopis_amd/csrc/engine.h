@@ -82,16 +82,17 @@ void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_orde
                           uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s);
 void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                                   const int* active, hipStream_t s);
-void launch_trmm_LZ(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
+
 
 // kernels_linalg.hip
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s);
 void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
-int wcov_num_tiles(int cs);
-size_t wcov_workspace_doubles(int B, int cs, int ksplit);
-void launch_wcov(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                 int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s);
+// kernels_mfma.hip
+void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
+size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
+void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
+                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s);
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);
 

@@ -65,7 +65,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         time_end();
         if (pol == MPOPIS_POL_MUSIGMAAISMPPI) {
             time_begin(4);
-            launch_wcov(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, 0.0, 10e-9, d_active, stream);
+            launch_wcov_mfma(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, 0.0, 10e-9, d_active, stream);
             time_end();
         }
         hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);   // pol.U += μ′
@@ -87,7 +87,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         time_end();
         time_begin(4);
         launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, K, 1, d_active, stream);   // mean_and_cov(E[:,idx], 2): corrected
-        launch_wcov(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream);
+        launch_wcov_mfma(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream);
         time_end();
         hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
         return MPOPIS_OK;
@@ -101,7 +101,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
             if (cfg.sigma_est != MPOPIS_SIGMA_EST_MLE) { err = "Σ_est :ss is not implemented on the device yet (use :mle)"; return MPOPIS_ERR_ARG; }
             time_begin(4);
             launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
-            launch_wcov(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
+            launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
             time_end();
             hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
             return MPOPIS_OK;

@@ -136,8 +136,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
-    h->ksplit = std::max(1, std::min(16, K / 256));
-    rc |= dalloc(h, &h->d_part, wcov_workspace_doubles(B, cs, h->ksplit));
+    h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 1024 / B)));   // ~2-4 workgroups per CU in the scatter kernel
+    rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
     if (cfg->policy == MPOPIS_POL_CMAMPPI) {
         rc |= dalloc(h, &h->d_cma_scal, (size_t)B * 8); rc |= dalloc(h, &h->d_cma_vec, (size_t)B * 3 * cs); rc |= dalloc(h, &h->d_sig2, B);
         rc |= dalloc(h, &h->d_cma_ws, (size_t)K); rc |= dalloc(h, &h->d_cnorm, B);
@@ -530,7 +530,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
         } else {
             launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
         }
-        if (!dsc) launch_trmm_LZ(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
+        if (!dsc) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
         time_end();
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active);

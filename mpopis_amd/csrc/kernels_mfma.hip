@@ -1,0 +1,204 @@
+// kernels_mfma.hip -- the two dense FP64 contractions of the AIS loop on the CDNA4 matrix cores
+// (v_mfma_f64_16x16x4_f64):
+//   E = L * Z              unwhiten! of rand(rng, MvNormal(Σ′), K)        src/mppi_mpopi_policies.jl:448,556,724,797
+//   Σ′ = X W X' / den + εI  StatsBase.mean_and_cov (weighted / resampled) :730-733,:806-808; cov(elite') :464
+// These are the only real contractions on the path (2·cs²·K flop each: 82 MFLOP at cs=100,K=4096, 737 MFLOP at
+// cs=300).  On MI355X the FP64 MFMA rate equals the FP64 vector rate (78.6 TF), so the win is operand traffic and
+// issue slots: one A and one B register pair per lane feed 2048 flops.
+// Fragment layout (f64 16x16x4): A lane l = A[i=l&15][k=l>>4]; B lane l = B[k=l>>4][j=l&15];
+// D lane l, reg r = D[row=(l>>4)+4r][col=l&15].
+#include "engine.h"
+
+namespace mpopis {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kTrmmTiles = 8;       // row tiles (of 16) per workgroup pass => 32 accumulator VGPR pairs
+
+// E[b][i][k] = sum_{j<=i} L[b][i][j] Z[b][j][k];  L n x n column-major lower (upper part stored as zeros);
+// Z, E [n][K].  grid (ceil(K/64), row groups, B), 4 waves; wave = 16 samples x (<= 8 row tiles).
+__global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
+                                                      double* __restrict__ E, int n, int K, const int* active) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k0 = (blockIdx.x * 4 + wv) * 16;
+    if (k0 >= K) return;
+    const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
+    const int nt_total = (n + 15) / 16;
+    const int nt = min(kTrmmTiles, nt_total - t0);
+    const double* Lb = L + (size_t)b * Lstride;
+    const double* Zb = Z + (size_t)b * n * K;
+    double* Eb = E + (size_t)b * n * K;
+    const int li = lane & 15, lk = lane >> 4;
+    const int kcol = min(k0 + li, K - 1);
+    v4f64 acc[kTrmmTiles];
+#pragma unroll
+    for (int t = 0; t < kTrmmTiles; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int jend = min(n, (t0 + nt) * 16);                   // L is lower triangular: j <= i
+    for (int j0 = 0; j0 < jend; j0 += 16) {                    // one 16-column chunk of L = 4 MFMA k-steps
+        double bz[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * q + lk; bz[q] = (j < n) ? Zb[(size_t)j * K + kcol] : 0.0; }
+        const int tfirst = max(0, j0 / 16 - t0);                // row tiles above the chunk's block row are all zero
+#pragma unroll
+        for (int t = 0; t < kTrmmTiles; ++t) {
+            if (t >= tfirst && t < nt) {                        // wave-uniform
+                const int i = (t0 + t) * 16 + li;
+                double al[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * q + lk; al[q] = (i < n && j < n) ? Lb[(size_t)i + (size_t)j * n] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], bz[q], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (k0 + li < K) {
+#pragma unroll
+        for (int t = 0; t < kTrmmTiles; ++t) {
+            if (t < nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = (t0 + t) * 16 + lk + 4 * r;
+                    if (i < n) Eb[(size_t)i * K + k0 + li] = acc[t][r];
+                }
+            }
+        }
+    }
+}
+
+void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL(k_trmm_LZ_mfma, dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scatter matrix partials.  A workgroup (4 waves) owns a group of <= 28 lower-triangular 16x16 tile pairs
+// (7 per wave) and one K split; it streams its k range in chunks staged through LDS as centred rows
+// Xs[row][kk] (row stride kc+2 doubles => conflict-free ds_read_b64 in the MFMA operand pattern).
+// part[b][split][pair][lane*4 + r]
+// ---------------------------------------------------------------------------------------------
+constexpr int kPairsPerWave = 7;
+constexpr int kPairsPerBlock = 4 * kPairsPerWave;
+
+__device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q -> (ta >= tb), row-major lower enumeration
+    int a = 0;
+    while (q >= a + 1) { q -= a + 1; ++a; }
+    *ta = a; *tb = q;
+}
+
+__global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
+                                                           const double* __restrict__ mu, double* __restrict__ part, int cs, int K, int m,
+                                                           int kc, int ksplit, int npairs, const int* active) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nt = (cs + 15) / 16, rows_pad = nt * 16;
+    const int S = kc + 2;                                       // LDS row stride (doubles), S = 2 (mod 32) for kc = 64
+    double* Xs = smem;                                          // [rows_pad][S]
+    double* ws = smem + (size_t)rows_pad * S;                   // [kc]
+    const double* Xb = X + (size_t)b * cs * K;
+    const double* wb = w ? w + (size_t)b * K : nullptr;
+    const int32_t* ib = idx ? idx + (size_t)b * K : nullptr;
+    const double* mub = mu + (size_t)b * cs;
+    // this wave's tile pairs
+    int pa[kPairsPerWave], pb[kPairsPerWave];
+    const int qbase = blockIdx.y * kPairsPerBlock + wv * kPairsPerWave;
+#pragma unroll
+    for (int p = 0; p < kPairsPerWave; ++p) {
+        if (qbase + p < npairs) decode_pair(qbase + p, &pa[p], &pb[p]); else { pa[p] = 0; pb[p] = 0; }   // dummy tile, result dropped
+    }
+    v4f64 acc[kPairsPerWave];
+#pragma unroll
+    for (int p = 0; p < kPairsPerWave; ++p) acc[p] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int per = ((m + ksplit - 1) / ksplit + kc - 1) / kc * kc;          // k range per split, multiple of kc
+    const int kbeg = blockIdx.x * per, kend = min(m, kbeg + per);
+    for (int c0 = kbeg; c0 < kend; c0 += kc) {
+        // stage: centred rows, zero padded
+        for (int e = threadIdx.x; e < rows_pad * kc; e += 256) {
+            const int kk = e % kc, row = e / kc;
+            const int kq = c0 + kk;
+            double v = 0.0;
+            if (kq < kend && row < cs) { const int col = ib ? ib[kq] : kq; v = Xb[(size_t)row * K + col] - mub[row]; }
+            Xs[(size_t)row * S + kk] = v;
+        }
+        for (int kk = threadIdx.x; kk < kc; kk += 256) {
+            const int kq = c0 + kk;
+            ws[kk] = (kq < kend) ? (wb ? wb[ib ? ib[kq] : kq] : 1.0) : 0.0;
+        }
+        __syncthreads();
+        for (int kk0 = 0; kk0 < kc; kk0 += 4) {
+            const double wk = ws[kk0 + lk];
+#pragma unroll
+            for (int p = 0; p < kPairsPerWave; ++p) {
+                const double av = Xs[(size_t)(pa[p] * 16 + li) * S + kk0 + lk] * wk;          // (x_a - μ_a) w_k
+                const double bv = Xs[(size_t)(pb[p] * 16 + li) * S + kk0 + lk];               // (x_b - μ_b)
+                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[p], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < kPairsPerWave; ++p) {
+        if (qbase + p < npairs) {
+            double* pp = part + (((size_t)b * ksplit + blockIdx.x) * npairs + (qbase + p)) * 256 + lane * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[r] = acc[p][r];
+        }
+    }
+}
+
+// S = (1/den) sum_splits part + ridge*I, written symmetric (lower triangle drives both halves)
+__global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
+                                                          int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active) {
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    __shared__ double sh[4];
+    __shared__ double sden;
+    if (den == 0.0) {                                           // Σ_k w_k (ProbabilityWeights: uncorrected)
+        double sacc = 0.0;
+        for (int k = threadIdx.x; k < K; k += 256) sacc += w[(size_t)b * K + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sacc;
+        __syncthreads();
+        if (threadIdx.x == 0) sden = sh[0] + sh[1] + sh[2] + sh[3];
+        __syncthreads();
+    } else { if (threadIdx.x == 0) sden = den; __syncthreads(); }
+    const double inv = 1 / sden;
+    const int q = blockIdx.x;
+    int ta, tb;
+    decode_pair(q, &ta, &tb);
+    const int e = threadIdx.x;                                  // e = lane*4 + r  (lane 0..63, r 0..3)
+    const int lane = e >> 2, r = e & 3;
+    const int ia = ta * 16 + (lane >> 4) + 4 * r, ibb = tb * 16 + (lane & 15);
+    if (ia >= cs || ibb >= cs) return;
+    if (ta == tb && ibb > ia) return;
+    double v = 0.0;
+    for (int sp = 0; sp < ksplit; ++sp) v += part[(((size_t)b * ksplit + sp) * npairs + q) * 256 + e];
+    v = v * inv;
+    if (ia == ibb) v += ridge;
+    Sg[(size_t)b * cs * cs + (size_t)ia + (size_t)ibb * cs] = v;
+    Sg[(size_t)b * cs * cs + (size_t)ibb + (size_t)ia * cs] = v;
+}
+
+static int wcov_kc(int cs) { return cs <= 128 ? 64 : 16; }
+size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
+    const int nt = (cs + 15) / 16;
+    return (size_t)B * ksplit * (nt * (nt + 1) / 2) * 256;
+}
+void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
+                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s) {
+    const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
+    const int kc = wcov_kc(cs);
+    const size_t lds = ((size_t)nt * 16 * (kc + 2) + kc) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_wcov_mfma_partial, dim3(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B), dim3(256), lds, s,
+                       X, w, idx, mu, part, cs, K, m, kc, ksplit, npairs, active);
+    hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active);
+}
+
+}  // namespace mpopis

@@ -31,7 +31,7 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     const double u2 = ((double)(b >> 11) + 0.5) * two_m53;
     const double R = sqrt(-2.0 * log(u1));
     double s, c;
-    sincos(kTwoPi * u2, &s, &c);
+    sincospi(2.0 * u2, &s, &c);                                 // = sin/cos(2π u2), no Payne-Hanek reduction
     *z0 = R * c; *z1 = R * s;
 }
 
@@ -57,9 +57,33 @@ __global__ void __launch_bounds__(256) k_sample_normal(double* __restrict__ Z, i
     Z[((size_t)b * cs + r) * K + k] = z;
 }
 
+// Pair version: one Philox call + one Box-Muller per TWO normals.  Needs the two members of a draw pair
+// (linear indices 2p, 2p+1) to sit in adjacent rows of the same sample: cs even (G order) / as even (:mppi).
+__global__ void __launch_bounds__(256) k_sample_normal_pair(double* __restrict__ Z, int cs, int K, int as, int mppi_order,
+                                                            const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                                                            const double* dscale, const int* active) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r = 2 * blockIdx.y;                               // rows r, r+1
+    if (k >= K) return;
+    uint64_t lin;
+    if (mppi_order) { const int t = r / as, a = r - t * as; lin = ((uint64_t)t * K + k) * as + a; }
+    else lin = (uint64_t)k * cs + r;
+    double z0, z1;
+    philox_normal_pair(seeds[b], slo, shi, lin >> 1, &z0, &z1);
+    if (dscale) { z0 *= dscale[(size_t)b * cs + r]; z1 *= dscale[(size_t)b * cs + r + 1]; }
+    Z[((size_t)b * cs + r) * K + k] = z0;
+    Z[((size_t)b * cs + r + 1) * K + k] = z1;
+}
+
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
                           uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
+    const bool pairable = mppi_order ? (as % 2 == 0) : (cs % 2 == 0);
+    if (pairable)
+        hipLaunchKernelGGL(k_sample_normal_pair, dim3((K + 255) / 256, cs / 2, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
+    else
+        hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
 }
 
 // resampling draws for :pmcmppi (rand(rng, Categorical(ws), K), :805): i uniform in [0,K), u in [0,1)
@@ -82,41 +106,6 @@ __global__ void __launch_bounds__(256) k_sample_resample_draws(int32_t* di, doub
 void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                                   const int* active, hipStream_t s) {
     hipLaunchKernelGGL(k_sample_resample_draws, dim3((K + 255) / 256, B), dim3(256), 0, s, di, du, K, seeds, slo, shi, active);
-}
-
-// E = L*Z, L lower-triangular n x n column-major per slot (Lstride = n*n, or 0 when shared),
-// Z,E [n][K].  First-cut FP64 VALU kernel: 16 rows x 256 samples per workgroup, L through the scalar
-// cache.  In-place is NOT allowed (E != Z).
-constexpr int kTrmmRows = 16;
-__global__ void __launch_bounds__(256) k_trmm_LZ(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
-                                                 double* __restrict__ E, int n, int K, const int* active) {
-    const int b = blockIdx.z;
-    if (active && !active[b]) return;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = blockIdx.y * kTrmmRows;
-    const double* Lb = L + (size_t)b * Lstride;
-    const double* Zb = Z + (size_t)b * n * K;
-    double acc[kTrmmRows];
-#pragma unroll
-    for (int ii = 0; ii < kTrmmRows; ++ii) acc[ii] = 0.0;
-    const int kk = k < K ? k : K - 1;
-    const int jmax = min(n, i0 + kTrmmRows);
-    for (int j = 0; j < jmax; ++j) {
-        const double z = Zb[(size_t)j * K + kk];
-#pragma unroll
-        for (int ii = 0; ii < kTrmmRows; ++ii) {
-            const int i = i0 + ii;
-            const double l = (i < n && j <= i) ? Lb[(size_t)i + (size_t)j * n] : 0.0;
-            acc[ii] = fma(l, z, acc[ii]);
-        }
-    }
-    if (k < K) {
-#pragma unroll
-        for (int ii = 0; ii < kTrmmRows; ++ii) if (i0 + ii < n) E[((size_t)b * n + i0 + ii) * K + k] = acc[ii];
-    }
-}
-void launch_trmm_LZ(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_trmm_LZ, dim3((K + 255) / 256, (n + kTrmmRows - 1) / kTrmmRows, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active);
 }
 
 }  // namespace mpopis
