@@ -17,13 +17,18 @@ constexpr int kTrmmTiles = 8;       // row tiles (of 16) per workgroup pass => 3
 
 // E[b][i][k] = sum_{j<=i} L[b][i][j] Z[b][j][k];  L n x n column-major lower (upper part stored as zeros);
 // Z, E [n][K].  grid (ceil(K/64), row groups, B), 4 waves; wave = 16 samples x (<= 8 row tiles).
+// L is streamed in 16-column chunks through a double-buffered LDS panel shared by the 4 waves (one
+// barrier per chunk); the next chunk's global loads (L panel + Z operands) are in flight during the
+// current chunk's MFMAs.
+constexpr int kTrmmRows = kTrmmTiles * 16;          // 128 rows per pass
+constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 32) doubles: conflict-free operand reads
 __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
                                                       double* __restrict__ E, int n, int K, const int* active) {
+    __shared__ double Ls[2][16][kTrmmLd];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wv) * 16;
-    if (k0 >= K) return;
     const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
     const int nt_total = (n + 15) / 16;
     const int nt = min(kTrmmTiles, nt_total - t0);
@@ -32,28 +37,44 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
     double* Eb = E + (size_t)b * n * K;
     const int li = lane & 15, lk = lane >> 4;
     const int kcol = min(k0 + li, K - 1);
+    const bool wave_on = k0 < K;
     v4f64 acc[kTrmmTiles];
 #pragma unroll
     for (int t = 0; t < kTrmmTiles; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int jend = min(n, (t0 + nt) * 16);                   // L is lower triangular: j <= i
-    for (int j0 = 0; j0 < jend; j0 += 16) {                    // one 16-column chunk of L = 4 MFMA k-steps
-        double bz[4];
+    // staging map: thread -> row si of the pass, columns sj + 2u (u < 8) of the chunk
+    const int si = threadIdx.x & (kTrmmRows - 1), sj = threadIdx.x >> 7;
+    const int gi = t0 * 16 + si, gic = min(gi, n - 1);
+    double lreg[8], bz[4];
+    auto load_chunk = [&](int j0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * q + lk; bz[q] = (j < n) ? Zb[(size_t)j * K + kcol] : 0.0; }
+        // unconditional loads from clamped addresses (a predicated load costs an exec-masked block + vmcnt(0) each);
+        // out-of-range / upper-triangle entries are zeroed when the chunk is written to LDS / used
+        for (int u = 0; u < 8; ++u) { const int j = min(j0 + sj + 2 * u, n - 1); lreg[u] = Lb[(size_t)gic + (size_t)j * n]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int j = min(j0 + 4 * q + lk, n - 1); bz[q] = Zb[(size_t)j * K + kcol]; }
+    };
+    load_chunk(0);
+    int buf = 0;
+    for (int j0 = 0; j0 < jend; j0 += 16, buf ^= 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + sj + 2 * u; Ls[buf][sj + 2 * u][si] = (gi < n && j < n && j <= gi) ? lreg[u] : 0.0; }
+        double bc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * q + lk < n) ? bz[q] : 0.0;
+        __syncthreads();
+        if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
         const int tfirst = max(0, j0 / 16 - t0);                // row tiles above the chunk's block row are all zero
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
             if (t >= tfirst && t < nt) {                        // wave-uniform
-                const int i = (t0 + t) * 16 + li;
-                double al[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int j = j0 + 4 * q + lk; al[q] = (i < n && j < n) ? Lb[(size_t)i + (size_t)j * n] : 0.0; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], bz[q], acc[t], 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[buf][4 * q + lk][t * 16 + li], bc[q], acc[t], 0, 0, 0);
             }
         }
     }
-    if (k0 + li < K) {
+    if (wave_on && k0 + li < K) {
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
             if (t < nt) {
@@ -87,18 +108,21 @@ __device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q
     *ta = a; *tb = q;
 }
 
+template <int KC>
 __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
                                                            const double* __restrict__ mu, double* __restrict__ part, int cs, int K, int m,
-                                                           int kc, int ksplit, int npairs, const int* active) {
+                                                           int ksplit, int npairs, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = (cs + 15) / 16, rows_pad = nt * 16;
-    const int S = kc + 2;                                       // LDS row stride (doubles), S = 2 (mod 32) for kc = 64
+    constexpr int S = KC + 2;                                   // LDS row stride (doubles): conflict-free MFMA operand reads
+    constexpr int kMaxLd = (KC == 64) ? 28 : 32;                // staged elements per thread and chunk (cs <= 112 resp. 512 rows)
+    constexpr int kRowStep = 256 / KC;
     double* Xs = smem;                                          // [rows_pad][S]
-    double* ws = smem + (size_t)rows_pad * S;                   // [kc]
+    double* ws = smem + (size_t)rows_pad * S;                   // [KC]
     const double* Xb = X + (size_t)b * cs * K;
     const double* wb = w ? w + (size_t)b * K : nullptr;
     const int32_t* ib = idx ? idx + (size_t)b * K : nullptr;
@@ -113,30 +137,42 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
     v4f64 acc[kPairsPerWave];
 #pragma unroll
     for (int p = 0; p < kPairsPerWave; ++p) acc[p] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int per = ((m + ksplit - 1) / ksplit + kc - 1) / kc * kc;          // k range per split, multiple of kc
+    const int per = ((m + ksplit - 1) / ksplit + KC - 1) / KC * KC;          // k range per split, multiple of KC
     const int kbeg = blockIdx.x * per, kend = min(m, kbeg + per);
-    for (int c0 = kbeg; c0 < kend; c0 += kc) {
-        // stage: centred rows, zero padded
-        for (int e = threadIdx.x; e < rows_pad * kc; e += 256) {
-            const int kk = e % kc, row = e / kc;
-            const int kq = c0 + kk;
-            double v = 0.0;
-            if (kq < kend && row < cs) { const int col = ib ? ib[kq] : kq; v = Xb[(size_t)row * K + col] - mub[row]; }
-            Xs[(size_t)row * S + kk] = v;
+    // staging map: this thread always handles column kk of a chunk and rows r0 + u*kRowStep
+    const int skk = threadIdx.x % KC, sr0 = threadIdx.x / KC;
+    double xreg[kMaxLd], mureg[kMaxLd], wreg = 0.0;
+#pragma unroll
+    for (int u = 0; u < kMaxLd; ++u) mureg[u] = mub[min(sr0 + u * kRowStep, cs - 1)];
+    bool kin_cur = false;
+    auto load_chunk = [&](int c0) {                             // unconditional loads from clamped addresses
+        const int kq = min(c0 + skk, kend - 1);
+        const int col = ib ? ib[kq] : kq;
+        wreg = wb ? wb[col] : 1.0;
+#pragma unroll
+        for (int u = 0; u < kMaxLd; ++u) xreg[u] = Xb[(size_t)min(sr0 + u * kRowStep, cs - 1) * K + col];
+    };
+    // per-pair operand bases in the MFMA lane pattern (row = tile*16 + li, column offset lk)
+    const double* pA[kPairsPerWave]; const double* pB[kPairsPerWave];
+#pragma unroll
+    for (int p = 0; p < kPairsPerWave; ++p) { pA[p] = Xs + (size_t)(pa[p] * 16 + li) * S + lk; pB[p] = Xs + (size_t)(pb[p] * 16 + li) * S + lk; }
+    if (kbeg < kend) load_chunk(kbeg);
+    for (int c0 = kbeg; c0 < kend; c0 += KC) {
+        kin_cur = (c0 + skk) < kend;
+#pragma unroll
+        for (int u = 0; u < kMaxLd; ++u) {
+            const int row = sr0 + u * kRowStep;
+            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? xreg[u] - mureg[u] : 0.0;    // centred, zero padded
         }
-        for (int kk = threadIdx.x; kk < kc; kk += 256) {
-            const int kq = c0 + kk;
-            ws[kk] = (kq < kend) ? (wb ? wb[ib ? ib[kq] : kq] : 1.0) : 0.0;
-        }
+        if (sr0 == 0) ws[skk] = kin_cur ? wreg : 0.0;
         __syncthreads();
-        for (int kk0 = 0; kk0 < kc; kk0 += 4) {
+        if (c0 + KC < kend) load_chunk(c0 + KC);                // next chunk's loads fly during the MFMAs
+#pragma unroll
+        for (int kk0 = 0; kk0 < KC; kk0 += 4) {
             const double wk = ws[kk0 + lk];
 #pragma unroll
-            for (int p = 0; p < kPairsPerWave; ++p) {
-                const double av = Xs[(size_t)(pa[p] * 16 + li) * S + kk0 + lk] * wk;          // (x_a - μ_a) w_k
-                const double bv = Xs[(size_t)(pb[p] * 16 + li) * S + kk0 + lk];               // (x_b - μ_b)
-                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[p], 0, 0, 0);
-            }
+            for (int p = 0; p < kPairsPerWave; ++p)             // (x_a - μ_a) w_k  x  (x_b - μ_b)
+                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[p][kk0] * wk, pB[p][kk0], acc[p], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -184,7 +220,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     Sg[(size_t)b * cs * cs + (size_t)ibb + (size_t)ia * cs] = v;
 }
 
-static int wcov_kc(int cs) { return cs <= 128 ? 64 : 16; }
+static int wcov_kc(int cs) { return cs <= 112 ? 64 : 16; }
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
     const int nt = (cs + 15) / 16;
     return (size_t)B * ksplit * (nt * (nt + 1) / 2) * 256;
@@ -195,9 +231,14 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     const int kc = wcov_kc(cs);
     const size_t lds = ((size_t)nt * 16 * (kc + 2) + kc) * sizeof(double);
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_wcov_mfma_partial, dim3(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B), dim3(256), lds, s,
-                       X, w, idx, mu, part, cs, K, m, kc, ksplit, npairs, active);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B);
+    if (kc == 64) hipLaunchKernelGGL(k_wcov_mfma_partial<64>, grid, dim3(256), lds, s, X, w, idx, mu, part, cs, K, m, ksplit, npairs, active);
+    else          hipLaunchKernelGGL(k_wcov_mfma_partial<16>, grid, dim3(256), lds, s, X, w, idx, mu, part, cs, K, m, ksplit, npairs, active);
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active);
 }
 

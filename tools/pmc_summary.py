@@ -1,0 +1,45 @@
+"""Summarise rocprofv3 --pmc passes (gpurun_out/pmc_r01/*/pmc_counter_collection.csv) per kernel:
+mean counter value per dispatch and mean duration.  Writes profiles/r01_pmc_summary.csv and
+profiles/pmc_rollout.json (HBM bytes per launch of the rollout kernel, used by bench.py)."""
+import csv, glob, json, os, sys, collections
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(root, "*", "pmc_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+names = sorted({c for k in acc for c in acc[k]})
+rows = []
+for k in sorted(acc, key=lambda k: -sum(dur[k])):
+    if not k.startswith("mpopis::"):
+        continue
+    row = {"kernel": k, "dispatches_per_pass": len(dur[k]) // max(1, len(acc[k])), "avg_us": sum(dur[k]) / len(dur[k])}
+    for c in names:
+        v = acc[k].get(c)
+        row[c] = sum(v) / len(v) if v else ""
+    rows.append(row)
+os.makedirs("profiles", exist_ok=True)
+with open("profiles/r01_pmc_summary.csv", "w", newline="") as fo:
+    w = csv.DictWriter(fo, fieldnames=["kernel", "dispatches_per_pass", "avg_us"] + names)
+    w.writeheader()
+    w.writerows(rows)
+for r in rows[:8]:
+    print({k: (round(v, 1) if isinstance(v, float) else v) for k, v in r.items()})
+ro = [r for r in rows if "k_rollout_car" in r["kernel"]]
+if ro:
+    r = ro[0]
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of a
+    # wide (16 B/lane) coalesced stream; this kernel's E loads are 8 B/lane (512 B per wave instruction) -- calibrated below
+    # against the known byte count (the kernel reads E once: B*cs*K*8 bytes).
+    B, cs, K = 64, 100, 4096
+    known_read = B * cs * K * 8
+    fetch_kib, write_kib = r.get("FETCH_SIZE") or 0.0, r.get("WRITE_SIZE") or 0.0
+    out = {"kernel": r["kernel"], "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+           "known_read_bytes_per_launch": known_read, "fetch_raw_bytes": fetch_kib * 1024,
+           "fetch_calibration_ratio_known_over_raw": known_read / (fetch_kib * 1024) if fetch_kib else None,
+           "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+           "note": "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md §HBM); 64 trials, K=4096, cs=100"}
+    json.dump(out, open("profiles/pmc_rollout.json", "w"), indent=1)
+    print(out)
