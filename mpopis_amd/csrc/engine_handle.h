@@ -34,7 +34,7 @@ struct mpopis_handle {
     double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr, *d_cnorm = nullptr;
     double *d_C = nullptr, *d_Y0 = nullptr, *d_Y1 = nullptr, *d_Z0 = nullptr, *d_Z1 = nullptr, *d_Tm = nullptr;
     unsigned long long* d_resid = nullptr;
-    static constexpr int kNsIters = 28;
+    static constexpr int kNsIters = 16;
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
     // Level-3 harness
     double* d_hs = nullptr; int* d_alive = nullptr; const int* alive_gate = nullptr; bool status_sticky = false;

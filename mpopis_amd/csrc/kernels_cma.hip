@@ -5,110 +5,59 @@
 //   Σ update + triu symmetrisation   :598-599
 // Σ^-0.5 is computed with the coupled Newton-Schulz iteration (Higham, "Functions of Matrices", eq. 6.35)
 //   Y0 = A/c, Z0 = I;  T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;   Y -> (A/c)^1/2, Z -> (A/c)^-1/2
-// which is all GEMM (batched FP64, LDS-tiled) and converges quadratically for SPD A once
-// c >= λmax (c = ||A||_inf).  It reaches the same matrix the eigen path does, to ~cond(A)*eps.
+// which is all GEMM (batched FP64 on the matrix cores, kernels_mfma.hip; every iterate is a polynomial in A, hence
+// symmetric) and converges quadratically for SPD A once c >= λmax (c = ||A||_inf).  It reaches the same matrix the
+// eigen path does, to ~cond(A)*eps.
 #include "engine.h"
 
 namespace mpopis {
-
-constexpr int kGT = 32;     // output tile
-constexpr int kGK = 32;     // contraction chunk
-
-// D = alpha * (A * B) + beta * I   for n x n column-major matrices, batched (stride n*n).
-// If resid != nullptr: atomically tracks max |I - A*B| per batch entry (as ordered uint64 bits).
-// done_prev (nullable): entries whose previous residual is below tol are copied through (D = passthru).
-__global__ void __launch_bounds__(256) k_gemm_nn(const double* __restrict__ A, const double* __restrict__ Bm, double* __restrict__ D,
-                                                 const double* __restrict__ passthru, int n, double alpha, double beta,
-                                                 unsigned long long* resid, const unsigned long long* resid_prev, double tol,
-                                                 const int* active) {
-    const int b = blockIdx.z;
-    if (active && !active[b]) return;
-    const size_t off = (size_t)b * n * n;
-    const int i0 = blockIdx.x * kGT, j0 = blockIdx.y * kGT;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    if (resid_prev && __longlong_as_double((long long)resid_prev[b]) < tol) {        // converged: pass through
-        if (passthru) {
-            for (int e = threadIdx.x; e < kGT * kGT; e += 256) {
-                const int i = i0 + (e % kGT), j = j0 + (e / kGT);
-                if (i < n && j < n) D[off + i + (size_t)j * n] = passthru[off + i + (size_t)j * n];
-            }
-        }
-        if (resid && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) resid[b] = resid_prev[b];
-        return;
-    }
-    __shared__ double sa[kGK][kGT + 1], sb[kGK][kGT + 1];
-    double acc[2][2] = {{0, 0}, {0, 0}};
-    for (int k0 = 0; k0 < n; k0 += kGK) {
-        for (int e = threadIdx.x; e < kGT * kGK; e += 256) {
-            const int ii = e % kGT, kk = e / kGT;                 // A tile: rows i0+ii (fast), cols k0+kk
-            sa[kk][ii] = (i0 + ii < n && k0 + kk < n) ? A[off + (i0 + ii) + (size_t)(k0 + kk) * n] : 0.0;
-            const int kb = e % kGK, jj = e / kGK;                 // B tile: rows k0+kb (fast), cols j0+jj
-            sb[kb][jj] = (k0 + kb < n && j0 + jj < n) ? Bm[off + (k0 + kb) + (size_t)(j0 + jj) * n] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int kk = 0; kk < kGK; ++kk) {
-            const double a0 = sa[kk][tx], a1 = sa[kk][tx + 16], b0 = sb[kk][ty], b1 = sb[kk][ty + 16];
-            acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
-            acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
-        }
-        __syncthreads();
-    }
-    double rmax = 0.0;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = i0 + tx + 16 * p, j = j0 + ty + 16 * q;
-            if (i < n && j < n) {
-                const double ab = acc[p][q];
-                rmax = fmax(rmax, fabs(((i == j) ? 1.0 : 0.0) - ab));
-                D[off + i + (size_t)j * n] = alpha * ab + ((i == j) ? beta : 0.0);
-            }
-        }
-    if (resid) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(&resid[b], (unsigned long long)__double_as_longlong(rmax));
-    }
-}
 
 __global__ void k_ns_resid_init(unsigned long long* r, int B, size_t n) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i < n) r[i] = (i < (size_t)B) ? 0x7FF0000000000000ull : 0ull;
 }
 
-// c[b] = ||A||_inf ; Y0 = A / c ; Z0 = I
-__global__ void __launch_bounds__(256) k_ns_init(const double* __restrict__ A, double* __restrict__ Y, double* __restrict__ Z, double* cnorm,
-                                                 int n, const int* active) {
+// c[b] = ||A||_inf (A symmetric: max column abs sum; one wave per column, coalesced)
+__global__ void __launch_bounds__(1024) k_ns_norm(const double* __restrict__ A, double* cnorm, int n, const int* active) {
     const int b = blockIdx.x;
     if (active && !active[b]) return;
-    __shared__ double sh[4];
-    __shared__ double c_sh;
+    __shared__ double sh[16];
     const size_t off = (size_t)b * n * n;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double mx = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int j = wv; j < n; j += 16) {
         double s = 0.0;
-        for (int j = 0; j < n; ++j) s += fabs(A[off + i + (size_t)j * n]);
+        for (int i = lane; i < n; i += 64) s += fabs(A[off + i + (size_t)j * n]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         mx = fmax(mx, s);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    if (lane == 0) sh[wv] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) { c_sh = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])); cnorm[b] = c_sh; }
-    __syncthreads();
-    const double inv = 1.0 / c_sh;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        Y[off + e] = A[off + e] * inv;
-        Z[off + e] = ((e % n) == (e / n)) ? 1.0 : 0.0;
-    }
+    if (threadIdx.x == 0) { double c = 0.0; for (int q = 0; q < 16; ++q) c = fmax(c, sh[q]); cnorm[b] = c; }
+}
+// Y0 = A / c ; Z0 = I
+__global__ void __launch_bounds__(256) k_ns_init(const double* __restrict__ A, double* __restrict__ Y, double* __restrict__ Z, const double* cnorm,
+                                                 int n, const int* active) {
+    const int b = blockIdx.z, j = blockIdx.y;
+    if (active && !active[b]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t e = (size_t)b * n * n + i + (size_t)j * n;
+    Y[e] = A[e] * (1.0 / cnorm[b]);
+    Z[e] = (i == j) ? 1.0 : 0.0;
 }
 
-// C = Z / sqrt(c)   (Z ~ (A/c)^-1/2)
-__global__ void __launch_bounds__(256) k_ns_finish(const double* __restrict__ Z, const double* cnorm, double* __restrict__ C, int n, const int* active) {
+// C = Z / sqrt(c)   (Z ~ (A/c)^-1/2).  Z lives in Z0 (even iterations) or Z1 (odd): the slot froze at the first
+// iteration `it` whose incoming residual was below tol; if it never converged the last iterate is used.
+__global__ void __launch_bounds__(256) k_ns_finish(const double* __restrict__ Z0, const double* __restrict__ Z1, const double* cnorm,
+                                                   const unsigned long long* resid, int iters, int B, double tol,
+                                                   double* __restrict__ C, int n, const int* active) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
+    int it = 0;
+    while (it < iters && !(__longlong_as_double((long long)resid[(size_t)it * B + b]) < tol)) ++it;
+    const double* Z = (it & 1) ? Z1 : Z0;
     const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;
     if (e < (size_t)n * n) C[(size_t)b * n * n + e] = Z[(size_t)b * n * n + e] / sqrt(cnorm[b]);
 }
@@ -118,21 +67,21 @@ void launch_inv_sqrt_spd(const double* A, double* C, double* Y0, double* Y1, dou
                          const int* active, hipStream_t s) {
     // resid[it][b]: max|I - ZY| seen by iteration it (ordered uint64 bits); row 0 = +inf ("not converged")
     hipLaunchKernelGGL(k_ns_resid_init, dim3(((size_t)(iters + 1) * B + 255) / 256), dim3(256), 0, s, resid, B, (size_t)(iters + 1) * B);
-    hipLaunchKernelGGL(k_ns_init, dim3(B), dim3(256), 0, s, A, Y0, Z0, cnorm, n, active);
-    const dim3 grid((n + kGT - 1) / kGT, (n + kGT - 1) / kGT, B);
-    const double tol = 1e-14;
+    hipLaunchKernelGGL(k_ns_norm, dim3(B), dim3(1024), 0, s, A, cnorm, n, active);
+    hipLaunchKernelGGL(k_ns_init, dim3((n + 255) / 256, n, B), dim3(256), 0, s, A, Y0, Z0, cnorm, n, active);
+    const double tol = 64.0 * n * 1.1e-16;                     // rounding floor of max|I - ZY| grows with n
     double *Yc = Y0, *Yn = Y1, *Zc = Z0, *Zn = Z1;
     for (int it = 0; it < iters; ++it) {
         unsigned long long* rprev = resid + (size_t)it * B;
         unsigned long long* rnew = resid + (size_t)(it + 1) * B;
         // T = 1.5 I - 0.5 Z Y  (+ residual max|I - ZY|)
-        hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, s, Zc, Yc, Tm, (const double*)nullptr, n, -0.5, 1.5, rnew, rprev, tol, active);
-        // Y' = Y T ; Z' = T Z   (pass-through copies once converged)
-        hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, s, Yc, Tm, Yn, Yc, n, 1.0, 0.0, (unsigned long long*)nullptr, rprev, tol, active);
-        hipLaunchKernelGGL(k_gemm_nn, grid, dim3(256), 0, s, Tm, Zc, Zn, Zc, n, 1.0, 0.0, (unsigned long long*)nullptr, rprev, tol, active);
+        launch_gemm_sym_mfma(Zc, Yc, Tm, B, n, -0.5, 1.5, rnew, rprev, tol, active, s);
+        // Y' = Y T ; Z' = T Z   (slots freeze once converged)
+        launch_gemm_sym_mfma(Yc, Tm, Yn, B, n, 1.0, 0.0, nullptr, rprev, tol, active, s);
+        launch_gemm_sym_mfma(Tm, Zc, Zn, B, n, 1.0, 0.0, nullptr, rprev, tol, active, s);
         std::swap(Yc, Yn); std::swap(Zc, Zn);
     }
-    hipLaunchKernelGGL(k_ns_finish, dim3(((size_t)n * n + 255) / 256, B), dim3(256), 0, s, Zc, cnorm, C, n, active);
+    hipLaunchKernelGGL(k_ns_finish, dim3(((size_t)n * n + 255) / 256, B), dim3(256), 0, s, Z0, Z1, cnorm, resid, iters, B, tol, C, n, active);
 }
 
 // Per-slot CMA scalars (d_cma_scal[b][8]): [0] σ  [1] temp_sum  [2] hσ  [3] ||pσ||  [4] ||C||_F²

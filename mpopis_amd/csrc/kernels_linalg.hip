@@ -31,8 +31,8 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {     // src is 
     return __hiloint2double(hi, lo);
 }
 
-template <bool LDS>
-__global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
+template <bool LDS, int NTHR>
+__global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
                                                int n, int npad, const double* scale, int* status, int* active) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int failed;
@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, siz
     double* W; int ldw, m;
     if (LDS) { W = smem; ldw = npad; m = npad; } else { W = Lb; ldw = n; m = n; }
     if (tid == 0) failed = 0;
-    for (int j = wv; j < m; j += 4)
+    for (int j = wv; j < m; j += NTHR / 64)
         for (int i = lane; i < m; i += 64) {
             double v;
             if (i < n && j < n) v = (i >= j) ? sc * Ab[(size_t)i + (size_t)j * n] : 0.0;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, siz
         if (failed) break;
         const int i1 = j0 + nb;              // first row below the panel
         // (2) panel solve: row i of L21 = A21[i,:] * L11^-T
-        for (int i = i1 + tid; i < m; i += 256) {
+        for (int i = i1 + tid; i < m; i += NTHR) {
             double x[kNB];
 #pragma unroll
             for (int c = 0; c < kNB; ++c) x[c] = (c < nb) ? W[(size_t)i + (size_t)(j0 + c) * ldw] : 0.0;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, siz
         const int ntile = (m + 15) / 16 - t1;
         if (nb == kNB && ntile > 0) {
             const int npair = ntile * (ntile + 1) / 2;
-            for (int q = wv; q < npair; q += 4) {
+            for (int q = wv; q < npair; q += NTHR / 64) {
                 int ta = 0, qq = q;
                 while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
                 const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
@@ -122,11 +122,11 @@ __global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, siz
                     const int ra = r0 + li, rb = c0 + li, col = j0 + kk * 4 + lk;
                     const double av = (ra < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0;
                     const double bv = (rb < m) ? W[(size_t)rb + (size_t)col * ldw] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = r0 + lk + 4 * r, c = c0 + li;
+                    const int i = r0 + li, c = c0 + lk + 4 * r;                               // D'[c - c0][i - r0]
                     if (i < m && c < m && i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
                 }
             }
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(256) k_potrf(const double* __restrict__ A, siz
         return;
     }
     if (LDS) {
-        for (int j = wv; j < n; j += 4)
+        for (int j = wv; j < n; j += NTHR / 64)
             for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
     }
 }
@@ -148,10 +148,10 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL(k_potrf<true>, dim3(B), dim3(256), bytes, s, A, Astride, L, n, npad, scale, status, active);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        hipLaunchKernelGGL((k_potrf<true, 256>), dim3(B), dim3(256), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
-        hipLaunchKernelGGL(k_potrf<false>, dim3(B), dim3(256), 0, s, A, Astride, L, n, n, scale, status, active);
+        hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), 0, s, A, Astride, L, n, n, scale, status, active);
     }
 }
 

@@ -22,11 +22,22 @@ constexpr int kTrmmTiles = 8;       // row tiles (of 16) per workgroup pass => 3
 // current chunk's MFMAs.
 constexpr int kTrmmRows = kTrmmTiles * 16;          // 128 rows per pass
 constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 32) doubles: conflict-free operand reads
+// TRI = true : L lower triangular (the sampler's E = L*Z).
+// TRI = false: general product D = alpha*(L*Z) + beta*I with K == n (Newton-Schulz step on symmetric iterates, where
+//              row-major == column-major), optional residual max|I - L*Z| (ordered-uint64 atomicMax) and freeze-on-
+//              convergence: a slot whose previous residual is below tol does nothing.
+template <bool TRI>
 __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
-                                                      double* __restrict__ E, int n, int K, const int* active) {
+                                                      double* __restrict__ E, int n, int K, const int* active,
+                                                      double alpha, double beta, unsigned long long* resid,
+                                                      const unsigned long long* resid_prev, double tol) {
     __shared__ double Ls[2][16][kTrmmLd];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
+    if (!TRI && resid_prev && __longlong_as_double((long long)resid_prev[b]) < tol) {
+        if (resid && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) resid[b] = resid_prev[b];
+        return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wv) * 16;
     const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
@@ -41,7 +52,7 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
     v4f64 acc[kTrmmTiles];
 #pragma unroll
     for (int t = 0; t < kTrmmTiles; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int jend = min(n, (t0 + nt) * 16);                   // L is lower triangular: j <= i
+    const int jend = TRI ? min(n, (t0 + nt) * 16) : n;         // lower triangular: j <= i
     // staging map: thread -> row si of the pass, columns sj + 2u (u < 8) of the chunk
     const int si = threadIdx.x & (kTrmmRows - 1), sj = threadIdx.x >> 7;
     const int gi = t0 * 16 + si, gic = min(gi, n - 1);
@@ -58,13 +69,13 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
     int buf = 0;
     for (int j0 = 0; j0 < jend; j0 += 16, buf ^= 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int j = j0 + sj + 2 * u; Ls[buf][sj + 2 * u][si] = (gi < n && j < n && j <= gi) ? lreg[u] : 0.0; }
+        for (int u = 0; u < 8; ++u) { const int j = j0 + sj + 2 * u; Ls[buf][sj + 2 * u][si] = (gi < n && j < n && (!TRI || j <= gi)) ? lreg[u] : 0.0; }
         double bc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * q + lk < n) ? bz[q] : 0.0;
         __syncthreads();
         if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
-        const int tfirst = max(0, j0 / 16 - t0);                // row tiles above the chunk's block row are all zero
+        const int tfirst = TRI ? max(0, j0 / 16 - t0) : 0;      // row tiles above the chunk's block row are all zero
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
             if (t >= tfirst && t < nt) {                        // wave-uniform
@@ -74,6 +85,7 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
             }
         }
     }
+    double rmax = 0.0;
     if (wave_on && k0 + li < K) {
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
@@ -81,16 +93,36 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = (t0 + t) * 16 + lk + 4 * r;
-                    if (i < n) Eb[(size_t)i * K + k0 + li] = acc[t][r];
+                    if (i < n) {
+                        if (TRI) Eb[(size_t)i * K + k0 + li] = acc[t][r];
+                        else {
+                            const double ab = acc[t][r], id = (i == k0 + li) ? 1.0 : 0.0;
+                            rmax = fmax(rmax, fabs(id - ab));
+                            Eb[(size_t)i * K + k0 + li] = alpha * ab + id * beta;
+                        }
+                    }
                 }
             }
         }
+    }
+    if (!TRI && resid) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
+        if (lane == 0) atomicMax(&resid[b], (unsigned long long)__double_as_longlong(rmax));
     }
 }
 
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL(k_trmm_LZ_mfma, dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active);
+    hipLaunchKernelGGL(k_trmm_LZ_mfma<true>, dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
+                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0);
+}
+// D = alpha*(A*Bm) + beta*I for symmetric n x n operands (batched, stride n*n), see k_trmm_LZ_mfma<false>
+void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, int n, double alpha, double beta,
+                          unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL(k_trmm_LZ_mfma<false>, dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, A, (size_t)n * n, Bm, D, n, n, active,
+                       alpha, beta, resid, resid_prev, tol);
 }
 
 // ---------------------------------------------------------------------------------------------
