@@ -65,7 +65,11 @@ MP_HD CarParams make_car_params(const double* p) {
 
 struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[i]^2 + y′[i]^2, derived)
     const double* x; const double* y; const double* w; const double* n2; int P;
+    // optional neighbour tables for the anchored nearest-point search (nullptr => always full scan):
+    // row i = the nbrw points closest to q_i in ascending distance (rank 0 = i itself), row stride nbrw + 1
+    const int* nbr_idx; const double* nbr_dist; int nbrw;
 };
+constexpr int kTrackNbrW = 16;
 
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 MP_HD double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
@@ -117,12 +121,12 @@ MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
 
 // Car state as the kernels carry it: the reference's 8 doubles plus sin/cos of psi and delta, which
 // are advanced by angle addition and never re-evaluated inside a rollout.
-struct CarState { double x, y, psi, Vx, Vy, r, delta, pedal, sp, cp, sd, cd; };
+struct CarState { double x, y, psi, Vx, Vy, r, delta, pedal, sp, cp, sd, cd; int near; };   // near: nearest track point of the last reward (-1: unknown)
 constexpr int kCarExt = 12;
 
 MP_HD void car_state_from8(CarState& c, const double* s) {     // the only place sin/cos are evaluated
     c.x = s[0]; c.y = s[1]; c.psi = s[2]; c.Vx = s[3]; c.Vy = s[4]; c.r = s[5]; c.delta = s[6]; c.pedal = s[7];
-    c.sp = sin(c.psi); c.cp = cos(c.psi); c.sd = sin(c.delta); c.cd = cos(c.delta);
+    c.sp = sin(c.psi); c.cp = cos(c.psi); c.sd = sin(c.delta); c.cd = cos(c.delta); c.near = -1;
 }
 MP_HD void car_state_to8(const CarState& c, double* s) {
     s[0] = c.x; s[1] = c.y; s[2] = c.psi; s[3] = c.Vx; s[4] = c.Vy; s[5] = c.r; s[6] = c.delta; s[7] = c.pedal;
@@ -247,20 +251,43 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     c.sp = sp; c.cp = cp; c.sd = sd; c.cd = cd;
 }
 
-// within_track(track, pos): car_racing_tracks.jl:68-92.  Track arrays are wave-uniform (scalar loads).
-MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out) {
-    // findmin over |q_i - p|^2 (:71-73) evaluated as |q_i|^2 - 2 q_i.p (+|p|^2, common to all i): 2 FMAs per
-    // point; ties/near-ties (< 1e-10 m^2 apart) may resolve differently from the literal form, which is
-    // harmless: the two candidates then share the projected segment.
-    int mi = 0;
+// within_track(track, pos): car_racing_tracks.jl:68-92.
+// findmin over |q_i - p|^2 (:71-73) is evaluated as v_i = |q_i|^2 - 2 q_i.p (|p|^2 is common to all i): 2 FMAs per
+// point; near-ties (< 1e-10 m^2 apart) may resolve differently from the literal form, which is harmless (the two
+// candidates then share the projected segment).  `anchor` (in/out, -1 = none) is the nearest point found by the
+// previous call of the same rollout: with D = |p - q_anchor|, every point farther than 2D from q_anchor is farther
+// than D from p (triangle inequality), so only the first few entries of the anchor's neighbour list need scanning --
+// the result is the exact argmin (ties -> lowest index, like findmin), typically after 3-5 instead of P evaluations.
+MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out, int* anchor) {
     const double m2x = -2.0 * px, m2y = -2.0 * py;
-    double best = fma(tk.y[0], m2y, fma(tk.x[0], m2x, tk.n2[0]));
-#pragma unroll 8
-    for (int i = 1; i < tk.P; ++i) {                                           // first minimum
-        const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
-        mi = (d < best) ? i : mi;
-        best = fmin(best, d);
+    int mi = -1;
+    double best = 0.0;
+    const int a0 = anchor ? *anchor : -1;
+    if (a0 >= 0 && tk.nbr_idx) {
+        const int S = tk.nbrw + 1;
+        mi = a0;
+        best = fma(tk.y[a0], m2y, fma(tk.x[a0], m2x, tk.n2[a0]));
+        const double bound = 2.0 * sqrt(fmax(best + fma(px, px, py * py), 0.0)) + 1e-6;
+        bool closed = false;
+        for (int c = 1; c < tk.nbrw; ++c) {
+            if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
+            const int j = tk.nbr_idx[a0 * S + c];
+            const double d = fma(tk.y[j], m2y, fma(tk.x[j], m2x, tk.n2[j]));
+            if (d < best || (d == best && j < mi)) { best = d; mi = j; }
+        }
+        if (!closed && tk.nbrw < tk.P) mi = -1;                 // list exhausted before the bound: full scan
     }
+    if (mi < 0) {
+        mi = 0;
+        best = fma(tk.y[0], m2y, fma(tk.x[0], m2x, tk.n2[0]));
+#pragma unroll 8
+        for (int i = 1; i < tk.P; ++i) {                                       // first minimum
+            const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
+            mi = (d < best) ? i : mi;
+            best = fmin(best, d);
+        }
+    }
+    if (anchor) *anchor = mi;
     const int im = (mi == 0) ? tk.P - 1 : mi - 1;                              // mod1 :75-76
     const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
     const double p1x = tk.x[mi], p1y = tk.y[mi];
@@ -283,9 +310,9 @@ MP_HD bool exceed_beta(const CarParams& p, double Vx, double Vy) {
     return (Vx < 0.0) && (fabs(Vy) < p.tan_blim * (-Vx));
 }
 
-MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y, double Vx, double Vy) {
+MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y, double Vx, double Vy, int* anchor = nullptr) {
     double dist;
-    const bool within = within_track(tk, x, y, &dist);
+    const bool within = within_track(tk, x, y, &dist, anchor);
     double rew = 0.0;
     if (!within) rew += -1000000.0;
     if (exceed_beta(p, Vx, Vy)) rew += -5000.0;                                // exceed_β :184-189

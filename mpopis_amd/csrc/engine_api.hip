@@ -118,7 +118,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     default_car_params(p); h->env.car = make_car_params(p);
     default_mc_params(p); h->env.mc = make_mc_params(p);
     for (int i = 0; i < kMaxAs; ++i) { h->env.lo[i] = -1.0; h->env.hi[i] = 1.0; }
-    h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0};
+    h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
     const int B = h->B, K = h->K, cs = h->cs;
     const size_t nn = (size_t)cs * cs;
     int rc = 0;
@@ -200,8 +200,22 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     HIPCHK(h, hipMemcpyAsync(d, x, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + P, y, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + 2 * P, w, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    // neighbour tables of the anchored nearest-point search: per point the kTrackNbrW closest points (ascending)
+    const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
+    std::vector<double> nd((size_t)P * S, 0.0); std::vector<int> ni((size_t)P * S, 0);
+    for (int i = 0; i < P; ++i) {
+        std::vector<std::pair<double, int>> v(P);
+        for (int j = 0; j < P; ++j) v[j] = {sqrt((x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i])), j};
+        v[i].first = -1.0;                                       // rank 0 = the point itself
+        std::sort(v.begin(), v.end());
+        for (int c = 0; c < W; ++c) { nd[(size_t)i * S + c] = std::max(v[c].first, 0.0); ni[(size_t)i * S + c] = v[c].second; }
+    }
+    double* dnd = nullptr; int* dni = nullptr;
+    if (dalloc(h, &dnd, nd.size()) || dalloc(h, &dni, ni.size())) return MPOPIS_ERR_HIP;
+    HIPCHK(h, hipMemcpyAsync(dnd, nd.data(), sizeof(double) * nd.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dni, ni.data(), sizeof(int) * ni.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P};
+    h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P, dni, dnd, W};
     return MPOPIS_OK;
 }
 

@@ -55,7 +55,7 @@ __global__ void k_harness_update(EnvDesc env, const double* x, const int* done_e
             d = fmin(d, sqrt(s[0] * s[0] + s[1] * s[1]));
             if (be > env.car.blim) ex_b = true;
             double dist;
-            if (!within_track(env.track, s[0], s[1], &dist)) within_t = false;
+            if (!within_track(env.track, s[0], s[1], &dist, nullptr)) within_t = false;
         }
         h[kH_vmean] += vmean / NC; h[kH_bmean] += bmean / NC;
         h[kH_vmax] = fmax(h[kH_vmax], vmax); h[kH_bmax] = fmax(h[kH_bmax], bmax);

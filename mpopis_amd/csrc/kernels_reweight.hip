@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64) k_env_query(EnvDesc env, const double* x, 
     for (int i = 0; i < NC; ++i) {
         const double* s = xb + 8 * i;
         double d;
-        const bool w = within_track(env.track, s[0], s[1], &d);
+        const bool w = within_track(env.track, s[0], s[1], &d, nullptr);
         if (!w) win = 0;
         if (dist) dist[(size_t)b * NC + i] = d;
         if (beta) beta[(size_t)b * NC + i] = atan2(s[4], s[3]);

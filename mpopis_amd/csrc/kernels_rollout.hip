@@ -18,13 +18,16 @@
 
 namespace mpopis {
 
-template <int NC>
-__global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
+// NC cars x SPB sample-waves per workgroup: the SPB*64 samples of a workgroup share one LDS copy of the track tables
+template <int NC, int SPB>
+__global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     const int lane = threadIdx.x & 63;
-    const int c = (NC > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
-    const int k = blockIdx.x * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = (NC > 1) ? wave % NC : 0;                   // car of this wave
+    const int g = wave / NC;                                  // sample group of this wave
+    const int k = (blockIdx.x * SPB + g) * 64 + lane;
     const int K = a.K, T = a.T;
     const bool valid = k < K;
     const int kk = valid ? k : K - 1;
@@ -35,17 +38,21 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
     // stage the (wave-uniform, read-only) track in LDS: uniform-address ds_reads broadcast to all lanes
     extern __shared__ __attribute__((aligned(16))) double sh_trk[];
     const int P = a.env.track.P;
-    for (int i = threadIdx.x; i < P; i += 64 * NC) {
+    const int W = a.env.track.nbrw, NS = P * (W + 1);
+    double* sh_nd = sh_trk + 4 * P;                           // neighbour distances [P][W+1]
+    int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);          // neighbour indices   [P][W+1]
+    for (int i = threadIdx.x; i < P; i += 64 * NC * SPB) {
         sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
         sh_trk[3 * P + i] = a.env.track.n2[i];
     }
+    for (int i = threadIdx.x; i < NS; i += 64 * NC * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P};
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W};
     CarState s;                                               // wave-uniform start state (+ sin/cos), scalar loads
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
         s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
-        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11];
+        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
     }
     const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
     const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
@@ -54,8 +61,8 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
     const double lo0 = a.env.lo[2 * c], hi0 = a.env.hi[2 * c], lo1 = a.env.lo[2 * c + 1], hi1 = a.env.hi[2 * c + 1];
     double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
 
-    __shared__ double sh_xy[2][NC][2][64];
-    __shared__ double sh_cost[NC][64];
+    __shared__ double sh_xy[2][SPB][NC][2][64];
+    __shared__ double sh_cost[SPB][NC][64];
 
     double cost = 0.0, cc = 0.0;
     double e0 = Eb[0], e1 = Eb[K];
@@ -65,16 +72,16 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
         const double a0 = clampd(v0, lo0, hi0), a1 = clampd(v1, lo1, hi1);     // get_model_controls
         car_action_step(p, s, a0, a1);
-        double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy);
+        double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
         if (NC > 1) {                                                          // multi-car_racing.jl:145-158
             const int buf = t & 1;
-            sh_xy[buf][c][0][lane] = s.x;
-            sh_xy[buf][c][1][lane] = s.y;
+            sh_xy[buf][g][c][0][lane] = s.x;
+            sh_xy[buf][g][c][1][lane] = s.y;
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
                 if (j > c) {
-                    const double dx = sh_xy[buf][j][0][lane] - s.x, dy = sh_xy[buf][j][1][lane] - s.y;
+                    const double dx = sh_xy[buf][g][j][0][lane] - s.x, dy = sh_xy[buf][g][j][1][lane] - s.y;
                     const double dd = sqrt(dx * dx + dy * dy);
                     rew += -dd;
                     if (dd <= 4.0) rew += -11000.0;
@@ -91,12 +98,12 @@ __global__ void __launch_bounds__(64 * NC) k_rollout_car(RolloutArgs a) {
     }
     cost += cc;
     if (NC > 1) {
-        sh_cost[c][lane] = cost;
+        sh_cost[g][c][lane] = cost;
         __syncthreads();
         if (c == 0) {
             double tot = cost;
 #pragma unroll
-            for (int j = 1; j < NC; ++j) tot += sh_cost[j][lane];
+            for (int j = 1; j < NC; ++j) tot += sh_cost[g][j][lane];
             if (valid) a.cost[(size_t)b * K + k] = tot;
         }
     } else {
@@ -148,17 +155,24 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
 }
 
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
-    dim3 grid((a.K + 63) / 64, a.B);
     if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
-        hipLaunchKernelGGL(k_rollout_mountaincar, grid, dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_rollout_mountaincar, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
         return;
     }
-    const size_t lds = (size_t)4 * a.env.track.P * sizeof(double);
+    const int P = a.env.track.P, W = a.env.track.nbrw;
+    const size_t lds = (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int));
+    // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 sample-waves share the LDS tables
+    const bool wide = a.K >= 1024;
+    const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B), g2((a.K + 127) / 128, a.B);
     switch (a.env.ncars) {
-        case 1: hipLaunchKernelGGL(k_rollout_car<1>, grid, dim3(64), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(k_rollout_car<2>, grid, dim3(128), lds, st, a); break;
-        case 3: hipLaunchKernelGGL(k_rollout_car<3>, grid, dim3(192), lds, st, a); break;
-        case 4: hipLaunchKernelGGL(k_rollout_car<4>, grid, dim3(256), lds, st, a); break;
+        case 1: if (wide) hipLaunchKernelGGL((k_rollout_car<1, 4>), g4, dim3(256), lds, st, a);
+                else      hipLaunchKernelGGL((k_rollout_car<1, 1>), g1, dim3(64), lds, st, a);
+                break;
+        case 2: if (wide) hipLaunchKernelGGL((k_rollout_car<2, 2>), g2, dim3(256), lds, st, a);
+                else      hipLaunchKernelGGL((k_rollout_car<2, 1>), g1, dim3(128), lds, st, a);
+                break;
+        case 3: hipLaunchKernelGGL((k_rollout_car<3, 1>), g1, dim3(192), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((k_rollout_car<4, 1>), g1, dim3(256), lds, st, a); break;
         default: break;
     }
 }
