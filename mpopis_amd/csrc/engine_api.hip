@@ -148,6 +148,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     h->h_status.assign(B, 0);
+    if (hipHostMalloc((void**)&h->h_pin, sizeof(double) * B * (h->as + 2)) != hipSuccess) h->h_pin = nullptr;
     // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
     const int n0 = (cfg->policy == MPOPIS_POL_MPPI) ? h->as : cs;
     std::vector<double> eye((size_t)n0 * n0, 0.0);
@@ -172,6 +173,7 @@ void mpopis_destroy(mpopis_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -401,7 +403,7 @@ int mpopis_policy_step(mpopis_handle* h, const mpopis_noise* noise, double* cont
     }
     int rc = h->policy_step_enqueue(noise && noise->Z);
     if (rc) return rc;
-    if (control) HIPCHK(h, hipMemcpyAsync(control, h->d_control, sizeof(double) * B * h->as, hipMemcpyDeviceToHost, h->stream));
+    if (control) HIPCHK(h, hipMemcpyAsync(h->h_pin ? h->h_pin : control, h->d_control, sizeof(double) * B * h->as, hipMemcpyDeviceToHost, h->stream));
     if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
     if (weights) HIPCHK(h, hipMemcpyAsync(weights, h->d_w, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
     if (E_out) {
@@ -415,8 +417,12 @@ int mpopis_policy_step(mpopis_handle* h, const mpopis_noise* noise, double* cont
         HIPCHK(h, hipMemcpyAsync(E_out, h->d_Z, sizeof(double) * B * per, hipMemcpyDeviceToHost, h->stream));
     }
     if (resample_idx0 && N > 1) HIPCHK(h, hipMemcpyAsync(resample_idx0, h->d_residx_log, sizeof(int32_t) * B * (N - 1) * K, hipMemcpyDeviceToHost, h->stream));
-    if (iters_run) HIPCHK(h, hipMemcpyAsync(iters_run, h->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
+    if (iters_run) HIPCHK(h, hipMemcpyAsync(h->h_pin ? (void*)(h->h_pin + (size_t)B * h->as) : (void*)iters_run, h->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
     rc = sync_status(h);
+    if (h->h_pin) {
+        if (control) memcpy(control, h->h_pin, sizeof(double) * B * h->as);
+        if (iters_run) memcpy(iters_run, h->h_pin + (size_t)B * h->as, sizeof(int) * B);
+    }
     HIPCHK(h, hipGetLastError());
     return rc;
 }

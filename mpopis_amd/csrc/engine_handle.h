@@ -41,6 +41,7 @@ struct mpopis_handle {
     // bookkeeping
     uint64_t mpc_step = 0;
     std::vector<int> h_status;
+    double* h_pin = nullptr;          // pinned staging for the small per-step outputs (control, iters)
     // timing
     bool timing = false;
     std::vector<hipEvent_t> events; std::vector<int> ev_slot; int ev_used = 0;

@@ -47,13 +47,26 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
     double* W; int ldw, m;
     if (LDS) { W = smem; ldw = npad; m = npad; } else { W = Lb; ldw = n; m = n; }
     if (tid == 0) failed = 0;
-    for (int j = wv; j < m; j += NTHR / 64)
-        for (int i = lane; i < m; i += 64) {
-            double v;
-            if (i < n && j < n) v = (i >= j) ? sc * Ab[(size_t)i + (size_t)j * n] : 0.0;
-            else v = (i == j) ? 1.0 : 0.0;
-            W[(size_t)i + (size_t)j * ldw] = v;
+    // copy in: batches of 8 unconditional (clamped) loads in flight per thread, select afterwards
+    for (int e0 = tid; e0 < m * m; e0 += NTHR * 8) {
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = min(e0 + u * NTHR, m * m - 1), i = e % m, j = e / m;
+            av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * NTHR;
+            if (e < m * m) {
+                const int i = e % m, j = e / m;
+                double v;
+                if (i < n && j < n) v = (i >= j) ? sc * av[u] : 0.0;
+                else v = (i == j) ? 1.0 : 0.0;
+                W[(size_t)i + (size_t)j * ldw] = v;
+            }
+        }
+    }
     __syncthreads();
 
     const int li = lane & 15, lk = lane >> 4;
@@ -70,8 +83,9 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
             for (int jj = 0; jj < kNB; ++jj) {
                 const double piv = bcast_lane(d[jj], jj);
                 if (!(piv > 0.0)) bad = true;
-                double rs = rsqrt(piv);
-                rs = rs * fma(-0.5 * piv * rs, rs, 1.5);            // one Newton step on top of the library rsqrt
+                double rs = __builtin_amdgcn_rsq(piv);              // v_rsq_f64 seed + 2 Newton steps (full precision)
+                rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+                rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
                 const double ljj = piv * rs;                        // sqrt(piv)
                 if (lane == jj) { d[jj] = ljj; rdiag[jj] = rs; } else if (lane > jj) d[jj] = d[jj] * rs;
 #pragma unroll

@@ -149,9 +149,10 @@ class Engine:
         return cost
 
     # ---- Level 2 ----------------------------------------------------------------------------------
-    def policy_step(self, Z=None, res_i0=None, res_u=None, want_E=False):
+    def policy_step(self, Z=None, res_i0=None, res_u=None, want_E=False, minimal=False):
         """pol(env) for all slots.  Z: injected normals, (B,N,K,cs) [G-variants] or (B,T,K,as) [:mppi];
-        None => device RNG.  Returns dict(control, cost, weights, iters_run, [E], [res_idx0])."""
+        None => device RNG.  Returns dict(control, cost, weights, iters_run, [E], [res_idx0]);
+        minimal=True copies back only control and iters_run (what `act = pol(env)` needs)."""
         B, K, cs, N = self.B, self.K, self.cs, self.N
         nz = None
         keep = []
@@ -167,10 +168,10 @@ class Engine:
                 nz.res_i0, nz.res_u = _i(ri), _d(ru)
                 keep += [ri, ru]
         control = np.zeros((B, self.as_))
-        cost = np.zeros((B, K))
-        w = np.zeros((B, K))
+        cost = None if minimal else np.zeros((B, K))
+        w = None if minimal else np.zeros((B, K))
         E = np.zeros(B * K * cs) if want_E else None
-        ridx = np.zeros((B, max(N - 1, 1), K), dtype=np.int32)
+        ridx = None if minimal else np.zeros((B, max(N - 1, 1), K), dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
         rc = self.L.mpopis_policy_step(self._h, C.byref(nz) if nz is not None else None, _d(control), _d(cost), _d(w),
                                        _d(E), _i(ridx), _i(iters))

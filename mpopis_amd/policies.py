@@ -82,7 +82,7 @@ class AbstractPathIntegralPolicy:
         Zb = None if Z is None else _f64(Z)[None]
         ri = None if res_i0 is None else np.asarray(res_i0)[None]
         ru = None if res_u is None else _f64(res_u)[None]
-        out = self._eng.policy_step(Zb, ri, ru, want_E=return_info)
+        out = self._eng.policy_step(Zb, ri, ru, want_E=return_info, minimal=not (return_info or self.params.log))
         if self.params.log:                                                                         # :140-143,:233-236
             self.logger.traj_costs = out["cost"][0]
             self.logger.traj_weights = out["weights"][0]

@@ -8,6 +8,7 @@
 #include <algorithm>
 using namespace mpopis;
 
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <class F> float timeit(F f, int reps, hipStream_t s) {

@@ -14,7 +14,7 @@ def run(policy, K, T, B, ncars=1, N=10, steps=5):
     tm = eng.timing_read()
     eng.timing_enable(False)
     ms2, rl2 = eng.bench_policy_steps(steps)
-    t0 = time.perf_counter(); out = eng.policy_step(); t1 = time.perf_counter()
+    t0 = time.perf_counter(); out = eng.policy_step(minimal=True); t1 = time.perf_counter()
     print(f"{policy} K={K} T={T} B={B} cars={ncars} N={eng.N}: {ms2/steps:.3f} ms/step  rollouts/s={rl2/(ms2*1e-3):.3e}  "
           f"mpc_steps/s={B*steps/(ms2*1e-3):.1f}  sync L2 call {1e3*(t1-t0):.3f} ms  iters={out['iters_run'][:4]}")
     print("   ", {k: (round(v[0]/max(v[1],1)*1e3,1), v[1]) for k, v in tm.items() if v[1]}, "(us avg, launches)")
