@@ -94,7 +94,10 @@ void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, i
                           unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s);
+                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
+                      const double* rscale = nullptr);
+void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
+void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s);
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);
 

@@ -98,10 +98,16 @@ int mpopis_handle::ais_update(int n, bool injected) {
         launch_elite_break(d_cost, d_order, B, K, m_elite, d_active, stream);                 // :458-461 / :566-569
         time_end();
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
-            if (cfg.sigma_est != MPOPIS_SIGMA_EST_MLE) { err = "Σ_est :ss is not implemented on the device yet (use :mle)"; return MPOPIS_ERR_ARG; }
             time_begin(4);
             launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
-            launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
+            if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS) {                                        // LinearShrinkage(DiagonalUnequalVariance(), :ss) :419
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 0.0, d_active, stream);
+                launch_inv_sd(d_Sig, d_gvec, B, cs, d_active, stream);                          // d_gvec is free here (γ row is rebuilt per iteration)
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_tmpS, d_part, B, cs, K, ksplit, 1.0, 0.0, d_active, stream, d_gvec);
+                launch_ss_shrink(d_Sig, d_tmpS, d_gvec, B, cs, m_elite, 10e-9, d_active, stream);
+            } else {
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
+            }
             time_end();
             hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
             return MPOPIS_OK;

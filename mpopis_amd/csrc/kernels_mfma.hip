@@ -140,9 +140,12 @@ __device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q
     *ta = a; *tb = q;
 }
 
-template <int KC>
+// SQ = true stages ((x - μ) * rscale[row])^2 instead of (x - μ): the fourth-moment scatter Σ_k z_a² z_b² needed by the
+// Schäfer-Strimmer shrinkage intensity (CE's Σ_est = :ss).
+template <int KC, bool SQ>
 __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
-                                                           const double* __restrict__ mu, double* __restrict__ part, int cs, int K, int m,
+                                                           const double* __restrict__ mu, const double* __restrict__ rscale,
+                                                           double* __restrict__ part, int cs, int K, int m,
                                                            int ksplit, int npairs, const int* active) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.z;
@@ -173,9 +176,12 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
     const int kbeg = blockIdx.x * per, kend = min(m, kbeg + per);
     // staging map: this thread always handles column kk of a chunk and rows r0 + u*kRowStep
     const int skk = threadIdx.x % KC, sr0 = threadIdx.x / KC;
-    double xreg[kMaxLd], mureg[kMaxLd], wreg = 0.0;
+    double xreg[kMaxLd], mureg[kMaxLd], rsreg[SQ ? kMaxLd : 1], wreg = 0.0;
 #pragma unroll
-    for (int u = 0; u < kMaxLd; ++u) mureg[u] = mub[min(sr0 + u * kRowStep, cs - 1)];
+    for (int u = 0; u < kMaxLd; ++u) {
+        mureg[u] = mub[min(sr0 + u * kRowStep, cs - 1)];
+        if (SQ) rsreg[u] = rscale[(size_t)b * cs + min(sr0 + u * kRowStep, cs - 1)];
+    }
     bool kin_cur = false;
     auto load_chunk = [&](int c0) {                             // unconditional loads from clamped addresses
         const int kq = min(c0 + skk, kend - 1);
@@ -194,7 +200,9 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) {
             const int row = sr0 + u * kRowStep;
-            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? xreg[u] - mureg[u] : 0.0;    // centred, zero padded
+            double v = xreg[u] - mureg[u];
+            if (SQ) { v *= rsreg[u]; v *= v; }
+            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : 0.0;                      // centred, zero padded
         }
         if (sr0 == 0) ws[skk] = kin_cur ? wreg : 0.0;
         __syncthreads();
@@ -252,25 +260,83 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     Sg[(size_t)b * cs * cs + (size_t)ibb + (size_t)ia * cs] = v;
 }
 
+// rs[b][a] = 1/sqrt(S[b][a][a])
+__global__ void __launch_bounds__(256) k_inv_sd(const double* __restrict__ Sg, double* __restrict__ rs, int cs, const int* active) {
+    const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
+    if ((active && !active[b]) || a >= cs) return;
+    rs[(size_t)b * cs + a] = 1.0 / sqrt(Sg[(size_t)b * cs * cs + (size_t)a * (cs + 1)]);
+}
+// LinearShrinkage(DiagonalUnequalVariance(), :ss) [third-party CovarianceEstimation.jl, restated from Schäfer & Strimmer 2005,
+// UNPINNED like the oracle's cov_ss_cols]: on standardised data r_ab = S_ab/(sd_a sd_b),
+//   λ* = Σ_{a≠b} Var^(r_ab) / Σ_{a≠b} r_ab²,  Var^(r_ab) = n/(n-1)³ (Q_ab - n r_ab²),  Q_ab = Σ_k z_ka² z_kb²;
+// S ← λ* diag(S) + (1-λ*) S  (+ ridge on the diagonal).  One workgroup per slot.
+__global__ void __launch_bounds__(256) k_ss_shrink(double* __restrict__ Sg, const double* __restrict__ Q, const double* __restrict__ rs,
+                                                   int cs, int m, double ridge, const int* active) {
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    __shared__ double sh[8];
+    __shared__ double lam_sh;
+    double* S = Sg + (size_t)b * cs * cs;
+    const double* Qb = Q + (size_t)b * cs * cs;
+    const double* r = rs + (size_t)b * cs;
+    double num = 0.0, den = 0.0;
+    for (int e = threadIdx.x; e < cs * cs; e += 256) {
+        const int a = e % cs, c = e / cs;
+        if (a == c) continue;
+        const double rab = S[e] * r[a] * r[c];
+        num += Qb[e] - (double)m * rab * rab;
+        den += rab * rab;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { num += __shfl_xor(num, o, 64); den += __shfl_xor(den, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = num; sh[4 + (threadIdx.x >> 6)] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        num = (sh[0] + sh[1] + sh[2] + sh[3]) * ((double)m / ((double)(m - 1) * (m - 1) * (m - 1)));
+        den = sh[4] + sh[5] + sh[6] + sh[7];
+        double lam = den > 0 ? num / den : 1.0;
+        lam_sh = fmin(fmax(lam, 0.0), 1.0);
+    }
+    __syncthreads();
+    const double keep = 1 - lam_sh;
+    for (int e = threadIdx.x; e < cs * cs; e += 256) {
+        const int a = e % cs, c = e / cs;
+        S[e] = (a == c) ? S[e] + ridge : S[e] * keep;
+    }
+}
+void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_ss_shrink, dim3(B), dim3(256), 0, s, S, Q, rs_ws, cs, m, ridge, active);
+}
+void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_inv_sd, dim3((cs + 255) / 256, B), dim3(256), 0, s, S, rs, cs, active);
+}
+
 static int wcov_kc(int cs) { return cs <= 112 ? 64 : 16; }
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
     const int nt = (cs + 15) / 16;
     return (size_t)B * ksplit * (nt * (nt + 1) / 2) * 256;
 }
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s) {
+                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale) {
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
     const size_t lds = ((size_t)nt * 16 * (kc + 2) + kc) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     const dim3 grid(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B);
-    if (kc == 64) hipLaunchKernelGGL(k_wcov_mfma_partial<64>, grid, dim3(256), lds, s, X, w, idx, mu, part, cs, K, m, ksplit, npairs, active);
-    else          hipLaunchKernelGGL(k_wcov_mfma_partial<16>, grid, dim3(256), lds, s, X, w, idx, mu, part, cs, K, m, ksplit, npairs, active);
+    if (rscale) {
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+    } else {
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+    }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active);
 }
 

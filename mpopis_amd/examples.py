@@ -62,11 +62,11 @@ def shard_trials(num_trials, rank, world):
 
 
 def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="cemppi", laps=2, num_samples=150, horizon=50,
-                        λ=10.0, α=1.0, U0=None, cov_mat=None, ais_its=10, λ_ais=20.0, ce_elite_threshold=0.8, ce_Σ_est="mle",
+                        λ=10.0, α=1.0, U0=None, cov_mat=None, ais_its=10, λ_ais=20.0, ce_elite_threshold=0.8, ce_Σ_est="ss",
                         cma_σ=0.75, cma_elite_threshold=0.8, seed=None, log_runs=True, device=0, dist=None, quiet=False):
     """Returns (records, summary) on rank 0 (None elsewhere).  Differences from the reference harness, all
-    forced by the platform: plotting/GIF options are not offered (out of scope), state noise σ is 0, and
-    ce_Σ_est defaults to :mle (the reference default :ss is a third-party estimator not on the device yet)."""
+    forced by the platform: plotting/GIF options are not offered (out of scope) and state noise σ is 0.
+    ce_Σ_est defaults to :ss like the reference (car_example.jl:66); :mle is the other supported estimator."""
     pt = str(policy_type).lstrip(":")
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1

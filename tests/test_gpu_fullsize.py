@@ -1,0 +1,95 @@
+"""BASELINE.json's full sizes (K=4096, H=50; 1 and 3 cars): properties that do not need the (slow) oracle
+on every sample, plus an oracle spot check on a subset of samples."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("ncars", [1, 3])
+def test_rollout_costs_full_size_properties(eng_mod, oracle, track, ncars):
+    K, T = 4096, 50
+    cs = 2 * ncars * T
+    rng = np.random.default_rng(7)
+    eng = eng_mod.Engine("car", ncars, "gmppi", K, T, batch=1, lam=10.0, cov=np.tile([0.0625, 0.1], ncars), track=track)
+    env = oracle.OracleEnv("car", ncars, track=track)
+    U = rng.uniform(-0.1, 0.1, cs)
+    E = rng.standard_normal((K, cs)) * np.tile([0.25, 0.32], ncars * T)
+    cost = eng.rollout_costs(U[None], E[None], x0=env.state[None])[0]
+    assert cost.shape == (K,) and np.all(np.isfinite(cost))
+    # (1) sample independence / permutation equivariance: cost[k] depends only on E[:,k]
+    perm = rng.permutation(K)
+    cost_p = eng.rollout_costs(U[None], E[perm][None], x0=env.state[None])[0]
+    assert np.array_equal(cost_p, cost[perm])
+    # (2) determinism
+    assert np.array_equal(eng.rollout_costs(U[None], E[None], x0=env.state[None])[0], cost)
+    # (3) clamp idempotence: perturbations beyond the action bounds do not change the cost
+    big = E.copy(); big[:64] = 50.0
+    sat = E.copy(); sat[:64] = 5.0
+    c1 = eng.rollout_costs(np.zeros((1, cs)), big[None], x0=env.state[None])[0]
+    c2 = eng.rollout_costs(np.zeros((1, cs)), sat[None], x0=env.state[None])[0]
+    assert np.array_equal(c1[:64], c2[:64]) and np.all(c1[:64] == c1[0])
+    # (4) shift equivalence: (U, E) and (U + d, E - d) give the same controls V = U + E
+    d = rng.uniform(-0.05, 0.05, cs)
+    c3 = eng.rollout_costs((U + d)[None], (E - d)[None], x0=env.state[None])[0]
+    assert np.max(np.abs(c3 - cost) / np.abs(cost)) < 1e-9
+    # (5) oracle spot check on a subset of the samples
+    pol = oracle.OraclePolicy("gmppi", env, 128, T, lam=10.0, U0=np.zeros(2 * ncars), cov=np.tile([0.0625, 0.1], ncars), nthreads=8)
+    ref = pol.simulate_model(U, E[:128].T)
+    assert np.max(np.abs(cost[:128] - ref) / np.abs(ref)) < 1e-8
+    eng.close()
+
+
+def test_policy_step_full_size_invariants(eng_mod, oracle, track):
+    """C5 shape: weights are a probability vector, the control is the clamped first weighted action,
+    U rolls (tail untouched), iteration counts = N, and the run is reproducible from the seed."""
+    K, T, N, B = 4096, 50, 10, 4
+    outs = []
+    for rep in range(2):
+        eng = eng_mod.Engine("car", 1, "musigmaaismppi", K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track, seed=99)
+        U0 = eng.get_U().copy()
+        o = eng.policy_step(None, want_E=True)
+        o["U"] = eng.get_U()
+        outs.append(o)
+        assert np.all(o["iters_run"] == N)
+        w = o["weights"]
+        assert np.all(w >= 0) and np.max(np.abs(w.sum(1) - 1)) < 1e-12
+        wc = U0 + np.einsum("bk,bkr->br", w, o["E"])                     # E already carries the (U - U_orig) shift
+        assert np.max(np.abs(np.clip(wc[:, :2], -1, 1) - o["control"])) < 1e-10
+        assert np.max(np.abs(o["U"][:, :-2] - wc[:, 2:])) < 1e-10 and np.array_equal(o["U"][:, -2:], U0[:, -2:])
+        c = o["cost"]
+        assert np.max(np.abs(w - np.exp(-(c - c.min(1, keepdims=True)) / 10.0) / np.exp(-(c - c.min(1, keepdims=True)) / 10.0).sum(1, keepdims=True))) < 1e-12
+        eng.close()
+    for k in ("control", "cost", "weights", "U"):
+        assert np.array_equal(outs[0][k], outs[1][k])
+    assert not np.array_equal(outs[0]["cost"][0], outs[0]["cost"][1])        # trials use different seeds
+
+
+def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
+    """Bit-exact resampling indices at K=4096 given identical weights and draws (alias table + sampling)."""
+    K = 4096
+    rng = np.random.default_rng(3)
+    cost = rng.uniform(300, 1200, K)
+    w = oracle.compute_weights(20.0, cost)
+    acc, al = oracle.make_alias_table(w)
+    di = rng.integers(0, K, K).astype(np.int32); du = rng.random(K)
+    ref = oracle.alias_sample(acc, al, di, du)
+    # engine: one pmcmppi iteration with injected draws; its iteration-1 indices depend only on (w, draws), and w on the costs.
+    T, N = 5, 2
+    eng = eng_mod.Engine("car", 1, "pmcmppi", K, T, batch=1, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track)
+    env = oracle.OracleEnv("car", 1, track=track)
+    pol = oracle.OraclePolicy("pmcmppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, lam_ais=20.0, nthreads=8)
+    Z = rng.standard_normal((N, K, 2 * T))
+    r = pol(env, Z, di[None], du[None])
+    g = eng.policy_step(Z[None], di[None, None], du[None, None])
+    assert np.array_equal(g["res_idx0"][0, 0], r["res_idx0"][0])
+    assert len(ref) == K
+    eng.close()

@@ -247,3 +247,23 @@ def test_level3_run_trials_mountaincar(eng_mod, oracle):
         assert rec[b, 1] == r["steps"], (rec[b], r)
         assert abs(rec[b, 0] - r["rew"]) < 1e-6 * abs(r["rew"])
     eng.close()
+
+
+def test_level2_cemppi_ss_estimator(eng_mod, oracle, track):
+    """CEMPPI with Σ_est = :ss (the car harness default, src/examples/car_example.jl:66): device shrinkage vs the oracle's
+    restatement of Schäfer-Strimmer (third-party formula, unpinned on both sides)."""
+    rng = np.random.default_rng(17)
+    K, T, N = 150, 12, 4
+    cs = 2 * T
+    env = oracle.OracleEnv("car", 1, track=track)
+    pol = oracle.OraclePolicy("cemppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, elite_threshold=0.8, sigma_est="ss")
+    eng = eng_mod.Engine("car", 1, "cemppi", K, T, batch=1, lam=10.0, ais_its=N, elite_threshold=0.8, sigma_est="ss", cov=[0.0625, 0.1], track=track)
+    for step in range(2):
+        Z = rng.standard_normal((N, K, cs))
+        ref = pol(env, Z)
+        got = eng.policy_step(Z[None], want_E=True)
+        assert got["iters_run"][0] == ref["iters_run"]
+        assert rel_err(got["cost"][0], ref["cost"]) < 1e-7
+        assert np.max(np.abs(got["E"][0].T - ref["E"])) < 1e-8
+        assert np.max(np.abs(got["control"][0] - ref["control"])) < 1e-8
+    eng.close()
