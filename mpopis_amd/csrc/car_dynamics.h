@@ -86,6 +86,18 @@ MP_HD double fast_rcp(double v) {
 #endif
 }
 
+// fma with all three operands in VGPRs.  hipcc turns `p = fma(p, x, C)` with a loop-invariant constant C into
+// `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, x` (one extra VALU op per Horner step); the explicit VOP3 form needs no copy.
+MP_HD double fma_v(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return fma(a, b, c);
+#endif
+}
+
 // sin/cos for |v| <= 0.25 (Taylor, truncation < 3e-21 relative)
 MP_HD void sincos_small(double v, double* s, double* c) {
     const double v2 = v * v;
@@ -136,14 +148,14 @@ MP_HD void car_state_to8(const CarState& c, double* s) {
 MP_HD void sincos_tiny(double v, double* s, double* c) {
     const double v2 = v * v;
     double ps = 1.0 / 362880.0;
-    ps = fma(ps, v2, -1.0 / 5040.0);
-    ps = fma(ps, v2, 1.0 / 120.0);
-    ps = fma(ps, v2, -1.0 / 6.0);
+    ps = fma_v(ps, v2, -1.0 / 5040.0);
+    ps = fma_v(ps, v2, 1.0 / 120.0);
+    ps = fma_v(ps, v2, -1.0 / 6.0);
     *s = fma(ps * v2, v, v);
     double pc = 1.0 / 40320.0;
-    pc = fma(pc, v2, -1.0 / 720.0);
-    pc = fma(pc, v2, 1.0 / 24.0);
-    pc = fma(pc, v2, -0.5);
+    pc = fma_v(pc, v2, -1.0 / 720.0);
+    pc = fma_v(pc, v2, 1.0 / 24.0);
+    pc = fma_v(pc, v2, -0.5);
     *c = fma(pc, v2, 1.0);
 }
 
