@@ -540,6 +540,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
             dsc = d_dscale;
         }
         double* Zdst = dsc ? d_E : d_Z;
+        bool fused = false;
         if (injected) {
             // B x N x (cs x K col-major) -> rows; slot stride N*per
             for (int b = 0; b < B; ++b) {
@@ -547,10 +548,14 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
                 else launch_transpose_in(d_Zin + ((size_t)b * N + (n - 1)) * per, Zdst + (size_t)b * per, 1, cs, K, stream);
             }
             if (dsc) launch_scale_rows(Zdst, dsc, B, cs, K, stream);
+        } else if (!dsc && pol != MPOPIS_POL_MPPI) {
+            // dense proposal: draw inside the unwhitening kernel when the shape allows it (no Z round trip through HBM)
+            fused = launch_sample_trmm_fused(Lp, Lstride, d_E, B, cs, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), d_active, stream);
+            if (!fused) launch_sample_normal(Zdst, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
         } else {
             launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
         }
-        if (!dsc) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
+        if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
         time_end();
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active);

@@ -8,6 +8,7 @@
 // Fragment layout (f64 16x16x4): A lane l = A[i=l&15][k=l>>4]; B lane l = B[k=l>>4][j=l&15];
 // D lane l, reg r = D[row=(l>>4)+4r][col=l&15].
 #include "engine.h"
+#include "philox.h"
 
 namespace mpopis {
 
@@ -26,11 +27,16 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 // TRI = false: general product D = alpha*(L*Z) + beta*I with K == n (Newton-Schulz step on symmetric iterates, where
 //              row-major == column-major), optional residual max|I - L*Z| (ordered-uint64 atomicMax) and freeze-on-
 //              convergence: a slot whose previous residual is below tol does nothing.
-template <bool TRI>
+// RNG = true (with TRI): Z is never materialised -- every wave draws the 16 x 16 block of standard normals it needs for the
+//              current chunk from the Philox streams (same counters as k_sample_normal_pair, i.e. the same numbers), two
+//              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
+//              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
+struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; };
+template <bool TRI, bool RNG>
 __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
                                                       double* __restrict__ E, int n, int K, const int* active,
                                                       double alpha, double beta, unsigned long long* resid,
-                                                      const unsigned long long* resid_prev, double tol) {
+                                                      const unsigned long long* resid_prev, double tol, RngArgs rng) {
     __shared__ double Ls[2][16][kTrmmLd];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
@@ -57,13 +63,33 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
     const int si = threadIdx.x & (kTrmmRows - 1), sj = threadIdx.x >> 7;
     const int gi = t0 * 16 + si, gic = min(gi, n - 1);
     double lreg[8], bz[4];
+    const uint64_t seed = RNG ? rng.seeds[b] : 0;
+    auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4q+lk of the stream
+        double z0[2], z1[2];
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho) {
+            const int pr = lane + 64 * rho, smp = pr & 15, rp = pr >> 4;              // pair -> (sample, row pair)
+            const int row = j0 + 2 * rp, kk = min(k0 + smp, K - 1);
+            const uint64_t lin = (uint64_t)kk * n + min(row, n - 2);
+            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, &z0[rho], &z1[rho]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int src = li + 16 * (((2 * q) & 3) + (lk >> 1));
+            const double a0 = __shfl(z0[q >> 1], src, 64), a1 = __shfl(z1[q >> 1], src, 64);
+            bz[q] = (lk & 1) ? a1 : a0;
+        }
+    };
     auto load_chunk = [&](int j0) {
 #pragma unroll
         // unconditional loads from clamped addresses (a predicated load costs an exec-masked block + vmcnt(0) each);
         // out-of-range / upper-triangle entries are zeroed when the chunk is written to LDS / used
         for (int u = 0; u < 8; ++u) { const int j = min(j0 + sj + 2 * u, n - 1); lreg[u] = Lb[(size_t)gic + (size_t)j * n]; }
+        if (RNG) draw_chunk(j0);
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int j = min(j0 + 4 * q + lk, n - 1); bz[q] = Zb[(size_t)j * K + kcol]; }
+            for (int q = 0; q < 4; ++q) { const int j = min(j0 + 4 * q + lk, n - 1); bz[q] = Zb[(size_t)j * K + kcol]; }
+        }
     };
     load_chunk(0);
     int buf = 0;
@@ -114,15 +140,24 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
 
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL(k_trmm_LZ_mfma<true>, dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0);
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<true, false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
+                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{nullptr, 0, 0});
+}
+// E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
+bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                              const int* active, hipStream_t s) {
+    const int nt = (n + 15) / 16;
+    if ((n & 1) || nt > kTrmmTiles) return false;
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<true, true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
+                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{seeds, slo, shi});
+    return true;
 }
 // D = alpha*(A*Bm) + beta*I for symmetric n x n operands (batched, stride n*n), see k_trmm_LZ_mfma<false>
 void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, int n, double alpha, double beta,
                           unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL(k_trmm_LZ_mfma<false>, dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, A, (size_t)n * n, Bm, D, n, n, active,
-                       alpha, beta, resid, resid_prev, tol);
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<false, false>), dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, A, (size_t)n * n, Bm, D, n, n, active,
+                       alpha, beta, resid, resid_prev, tol, RngArgs{nullptr, 0, 0});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -143,7 +178,7 @@ __device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q
 // SQ = true stages ((x - μ) * rscale[row])^2 instead of (x - μ): the fourth-moment scatter Σ_k z_a² z_b² needed by the
 // Schäfer-Strimmer shrinkage intensity (CE's Σ_est = :ss).
 template <int KC, bool SQ>
-__global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
+__global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
                                                            const double* __restrict__ mu, const double* __restrict__ rscale,
                                                            double* __restrict__ part, int cs, int K, int m,
                                                            int ksplit, int npairs, const int* active) {
@@ -176,11 +211,15 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
     const int kbeg = blockIdx.x * per, kend = min(m, kbeg + per);
     // staging map: this thread always handles column kk of a chunk and rows r0 + u*kRowStep
     const int skk = threadIdx.x % KC, sr0 = threadIdx.x / KC;
-    double xreg[kMaxLd], mureg[kMaxLd], rsreg[SQ ? kMaxLd : 1], wreg = 0.0;
+    // !SQ: rows are staged UNcentred and the finish kernel subtracts μ μ' Σw (Σ w (x-μ)(x-μ)' = Σ w x x' - μ μ' Σw for
+    // μ = Σ w x / Σw; x and μ are O(0.1..1), so the cancellation costs ~1e-16 absolute) -- this frees 56 VGPRs per lane.
+    double xreg[kMaxLd], mureg[SQ ? kMaxLd : 1], rsreg[SQ ? kMaxLd : 1], wreg = 0.0;
+    if (SQ) {
 #pragma unroll
-    for (int u = 0; u < kMaxLd; ++u) {
-        mureg[u] = mub[min(sr0 + u * kRowStep, cs - 1)];
-        if (SQ) rsreg[u] = rscale[(size_t)b * cs + min(sr0 + u * kRowStep, cs - 1)];
+        for (int u = 0; u < kMaxLd; ++u) {
+            mureg[u] = mub[min(sr0 + u * kRowStep, cs - 1)];
+            rsreg[u] = rscale[(size_t)b * cs + min(sr0 + u * kRowStep, cs - 1)];
+        }
     }
     bool kin_cur = false;
     auto load_chunk = [&](int c0) {                             // unconditional loads from clamped addresses
@@ -200,8 +239,8 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) {
             const int row = sr0 + u * kRowStep;
-            double v = xreg[u] - mureg[u];
-            if (SQ) { v *= rsreg[u]; v *= v; }
+            double v = xreg[u];
+            if (SQ) { v = (v - mureg[u]) * rsreg[u]; v *= v; }
             if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : 0.0;                      // centred, zero padded
         }
         if (sr0 == 0) ws[skk] = kin_cur ? wreg : 0.0;
@@ -227,22 +266,25 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_partial(const double* __restr
 }
 
 // S = (1/den) sum_splits part + ridge*I, written symmetric (lower triangle drives both halves)
+// mu_corr != nullptr: the partials are the UNcentred scatter Σ w x x'; subtract μ μ' wtot (wtot = Σ of the weights used:
+// Σ_k w_k, or m for unweighted gathered columns)
 __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
-                                                          int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active) {
+                                                          int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
+                                                          const double* __restrict__ mu_corr, double wtot_unweighted) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
-    __shared__ double sden;
-    if (den == 0.0) {                                           // Σ_k w_k (ProbabilityWeights: uncorrected)
+    __shared__ double sden, swtot;
+    if (w) {                                                    // Σ_k w_k (ProbabilityWeights)
         double sacc = 0.0;
         for (int k = threadIdx.x; k < K; k += 256) sacc += w[(size_t)b * K + k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sacc;
         __syncthreads();
-        if (threadIdx.x == 0) sden = sh[0] + sh[1] + sh[2] + sh[3];
+        if (threadIdx.x == 0) { swtot = sh[0] + sh[1] + sh[2] + sh[3]; sden = (den == 0.0) ? swtot : den; }
         __syncthreads();
-    } else { if (threadIdx.x == 0) sden = den; __syncthreads(); }
+    } else { if (threadIdx.x == 0) { sden = den; swtot = wtot_unweighted; } __syncthreads(); }
     const double inv = 1 / sden;
     const int q = blockIdx.x;
     int ta, tb;
@@ -254,6 +296,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     if (ta == tb && ibb > ia) return;
     double v = 0.0;
     for (int sp = 0; sp < ksplit; ++sp) v += part[(((size_t)b * ksplit + sp) * npairs + q) * 256 + e];
+    if (mu_corr) v = fma(-mu_corr[(size_t)b * cs + ia] * swtot, mu_corr[(size_t)b * cs + ibb], v);
     v = v * inv;
     if (ia == ibb) v += ridge;
     Sg[(size_t)b * cs * cs + (size_t)ia + (size_t)ibb * cs] = v;
@@ -337,7 +380,8 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
         if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
     }
-    hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active);
+    hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
+                       rscale ? (const double*)nullptr : mu, (double)m);
 }
 
 }  // namespace mpopis
