@@ -121,11 +121,12 @@ def main():
         per_launch = B * K
         ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
         ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")
-        if os.path.exists(pj):
+        traffic, valu_busy = None, None
+        pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")      # written by tools/pmc_summary.py from separate --pmc passes
+        if os.path.exists(pj) and B == 64:
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+                pm = json.load(open(pj))
+                traffic, valu_busy = pm.get("hbm_bytes_per_launch"), pm.get("valu_busy_frac")
             except Exception:
                 traffic = None
         out = {
@@ -139,8 +140,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1, 4>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
-                         "binding_resource": "FP64 VALU (not HBM): see fp64_*",
-                         "fp64_achieved_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS, "fp64_frac": ach_tf / FP64_PEAK_TFLOPS},
+                         "binding_resource": "FP64 VALU issue (not HBM, not MFMA); valu_busy_frac from the PMC pass in profiles/",
+                         "valu_busy_frac": valu_busy,
+                         "fp64_reference_algorithm_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+                         "fp64_reference_algorithm_frac": ach_tf / FP64_PEAK_TFLOPS,
+                         "note": "fp64_reference_* prices SURVEY 8(d)'s 3.5e5 flop-equivalents of the REFERENCE formulation per rollout; the kernel executes ~4x fewer (transcendental-free sub-step), so this can exceed 1"},
             "kernel_ms": {k: v[0] for k, v in tm.items() if v[1]},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -49,7 +49,8 @@ enum { MPOPIS_POL_MPPI = 0,            /* :mppi       MPPI_Policy      :107-216 
        MPOPIS_POL_MUSIGMAAISMPPI = 6,  /* :μΣaismppi  μΣAISMPPI_Policy :677-742 */
        MPOPIS_POL_PMCMPPI = 7 };       /* :pmcmppi    PMCMPPI_Policy   :748-817 */
 
-enum { MPOPIS_SIGMA_EST_MLE = 0, MPOPIS_SIGMA_EST_SS = 1 };   /* CEMPPI Σ_est :414-426 */
+enum { MPOPIS_SIGMA_EST_MLE = 0, MPOPIS_SIGMA_EST_SS = 1, MPOPIS_SIGMA_EST_LW = 2, MPOPIS_SIGMA_EST_RBLW = 3,
+       MPOPIS_SIGMA_EST_OAS = 4 };   /* CEMPPI Σ_est :414-426 (:mle exact; shrinkage estimators restate CovarianceEstimation.jl, unpinned) */
 
 /* Car parameter vector (20 doubles) = CarRacingEnvParams fields in declaration order
  * (src/envs/car_racing.jl:2-21) followed by dt, δt (:33-34).  MountainCar: 8 doubles

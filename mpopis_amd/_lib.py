@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmpopis_hip.so")
 ENV_MOUNTAINCAR, ENV_CAR = 0, 1
 POLICY_IDS = {"mppi": 0, "gmppi": 1, "imppi": 2, "cemppi": 3, "cmamppi": 4,
               "μaismppi": 5, "muaismppi": 5, "μΣaismppi": 6, "musigmaaismppi": 6, "pmcmppi": 7}
-SIGMA_EST_IDS = {"mle": 0, "ss": 1}
+SIGMA_EST_IDS = {"mle": 0, "ss": 1, "lw": 2, "rblw": 3, "oas": 4}
 ERR_ARG, ERR_NOT_PD, ERR_ACTION, ERR_HIP = -1, -2, -3, -4
 RECORD_LEN = 16
 

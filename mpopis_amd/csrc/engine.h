@@ -99,6 +99,8 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
                       const double* rscale = nullptr);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
+void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);
+void launch_fill_f64(double* p, double v, size_t n, hipStream_t s);
 void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s);
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);

@@ -100,9 +100,13 @@ int mpopis_handle::ais_update(int n, bool injected) {
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
             time_begin(4);
             launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
-            if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS) {                                        // LinearShrinkage(DiagonalUnequalVariance(), :ss) :419
+            if (cfg.sigma_est == MPOPIS_SIGMA_EST_RBLW || cfg.sigma_est == MPOPIS_SIGMA_EST_OAS) {   // DiagonalCommonVariance :421-423
                 launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 0.0, d_active, stream);
-                launch_inv_sd(d_Sig, d_gvec, B, cs, d_active, stream);                          // d_gvec is free here (γ row is rebuilt per iteration)
+                launch_common_shrink(d_Sig, B, cs, m_elite, cfg.sigma_est == MPOPIS_SIGMA_EST_OAS, 10e-9, d_active, stream);
+            } else if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS || cfg.sigma_est == MPOPIS_SIGMA_EST_LW) {   // DiagonalUnequalVariance :417-419
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 0.0, d_active, stream);
+                if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS) launch_inv_sd(d_Sig, d_gvec, B, cs, d_active, stream);   // d_gvec is free here (γ row is rebuilt per iteration)
+                else launch_fill_f64(d_gvec, 1.0, (size_t)B * cs, stream);                       // :lw = same intensity on the unstandardised data
                 launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_tmpS, d_part, B, cs, K, ksplit, 1.0, 0.0, d_active, stream, d_gvec);
                 launch_ss_shrink(d_Sig, d_tmpS, d_gvec, B, cs, m_elite, 10e-9, d_active, stream);
             } else {

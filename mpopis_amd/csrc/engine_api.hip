@@ -35,12 +35,6 @@ __global__ void k_bcast_f64(const double* s, double* d, size_t n, int B) {     /
     size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i < n) for (int b = 0; b < B; ++b) d[(size_t)b * n + i] = s[i];
 }
-__global__ void k_axpy_active(const double* x, double* y, const double* alpha, int n, const int* active) {   // y[b] += alpha[b]*x[b]
-    const int b = blockIdx.y; if (active && !active[b]) return;
-    const int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
-    const double a = alpha ? alpha[b] : 1.0;
-    y[(size_t)b * n + i] = y[(size_t)b * n + i] + a * x[(size_t)b * n + i];
-}
 __global__ void k_set_iters(int* iters, int n, const int* active, int B) { int b = blockIdx.x * 256 + threadIdx.x; if (b < B && (!active || active[b])) iters[b] = n; }
 
 static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }

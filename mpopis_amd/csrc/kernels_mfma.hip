@@ -313,6 +313,7 @@ __global__ void __launch_bounds__(256) k_inv_sd(const double* __restrict__ Sg, d
 // UNPINNED like the oracle's cov_ss_cols]: on standardised data r_ab = S_ab/(sd_a sd_b),
 //   λ* = Σ_{a≠b} Var^(r_ab) / Σ_{a≠b} r_ab²,  Var^(r_ab) = n/(n-1)³ (Q_ab - n r_ab²),  Q_ab = Σ_k z_ka² z_kb²;
 // S ← λ* diag(S) + (1-λ*) S  (+ ridge on the diagonal).  One workgroup per slot.
+// standardized = 0 gives the :lw variant (same intensity on the unstandardised scatter: rs == 1, Q = Σ_k xc_a² xc_b²).
 __global__ void __launch_bounds__(256) k_ss_shrink(double* __restrict__ Sg, const double* __restrict__ Q, const double* __restrict__ rs,
                                                    int cs, int m, double ridge, const int* active) {
     const int b = blockIdx.x;
@@ -347,6 +348,38 @@ __global__ void __launch_bounds__(256) k_ss_shrink(double* __restrict__ Sg, cons
         S[e] = (a == c) ? S[e] + ridge : S[e] * keep;
     }
 }
+// LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas): closed forms in tr(S), tr(S²) (Chen et al. 2010), F = tr(S)/p I
+__global__ void __launch_bounds__(256) k_common_shrink(double* __restrict__ Sg, int cs, int m, int oas, double ridge, const int* active) {
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    __shared__ double sh[8];
+    __shared__ double lam_sh, f_sh;
+    double* S = Sg + (size_t)b * cs * cs;
+    double tr = 0.0, tr2 = 0.0;
+    for (int e = threadIdx.x; e < cs * cs; e += 256) { const double v = S[e]; tr2 = fma(v, v, tr2); if (e % cs == e / cs) tr += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tr += __shfl_xor(tr, o, 64); tr2 += __shfl_xor(tr2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = tr; sh[4 + (threadIdx.x >> 6)] = tr2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tr = sh[0] + sh[1] + sh[2] + sh[3]; tr2 = sh[4] + sh[5] + sh[6] + sh[7];
+        const double p = cs, n = m, dd = tr2 - tr * tr / p;
+        double lam = oas ? ((1 - 2 / p) * tr2 + tr * tr) / ((n + 1 - 2 / p) * dd) : ((n - 2) / n * tr2 + tr * tr) / ((n + 2) * dd);
+        lam_sh = (dd > 0) ? fmin(fmax(lam, 0.0), 1.0) : 1.0;
+        f_sh = tr / p;
+    }
+    __syncthreads();
+    const double lam = lam_sh, f = f_sh;
+    for (int e = threadIdx.x; e < cs * cs; e += 256) {
+        const bool dg = (e % cs) == (e / cs);
+        S[e] = (1 - lam) * S[e] + (dg ? lam * f + ridge : 0.0);
+    }
+}
+void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_common_shrink, dim3(B), dim3(256), 0, s, S, cs, m, oas, ridge, active);
+}
+__global__ void __launch_bounds__(256) k_fill_f64(double* p, double v, size_t n) { const size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = v; }
+void launch_fill_f64(double* p, double v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_f64, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
 void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s) {
     hipLaunchKernelGGL(k_ss_shrink, dim3(B), dim3(256), 0, s, S, Q, rs_ws, cs, m, ridge, active);
 }

@@ -139,8 +139,6 @@ class CEMPPI_Policy(AbstractGMPPI_Policy):
         Σ_est = str(Σ_est).lstrip(":")
         if Σ_est not in ("mle", "lw", "ss", "rblw", "oas"):
             raise MPOPISError(ERR_ARG, "CEMPPI_Policy - Not a valid Σ estimation method")          # :425
-        if Σ_est not in ("mle", "ss"):
-            raise MPOPISError(ERR_ARG, "Σ_est=:%s (CovarianceEstimation.LinearShrinkage) is not implemented on the device; use :mle or :ss" % Σ_est)
         super().__init__(env, _extra=dict(ais_its=opt_its, elite_threshold=ce_elite_threshold, sigma_est=Σ_est), **kw)
         self.opt_its, self.ce_elite_threshold = opt_its, ce_elite_threshold
 

@@ -597,8 +597,16 @@ void orc_roll_U(orc_policy *pol, const double *wc, double *control) {
     }
 }
 
+/* Threads for the dense helpers below.  The reference gets these from multi-threaded BLAS/LAPACK (OpenBLAS under
+ * Julia); the naive loops here are at least spread over the same cores as the rollouts so the timed CPU baseline is
+ * not dominated by serial linear algebra. */
+static int g_dense_threads = 1;
+
 /* E = L*Z (unwhiten!, [3P] PDMats), Z and E cs x K col-major */
 static void lmul_LZ(int cs, int K, const double *L, const double *Z, double *E) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_dense_threads) schedule(static)
+#endif
     for (int k = 0; k < K; ++k)
         for (int i = 0; i < cs; ++i) {
             double v = 0.0;
@@ -666,6 +674,50 @@ static void cov_ss_cols(int cs, int m, const double *X, double *mean, double *S)
     free(sd);
 }
 
+/* LinearShrinkage(DiagonalUnequalVariance(), :lw) [3P, recalled: Ledoit & Wolf intensity for the diagonal target on the
+ * UNstandardised data: lambda* = sum_{i!=j} Var^(s_ij) / sum_{i!=j} s_ij^2, Var^(s_ij) = n/(n-1)^3 sum_k (w_kij - s_ij)^2,
+ * w_kij = xc_ki xc_kj].  UNPINNED. */
+static void cov_lw_cols(int cs, int m, const double *X, double *mean, double *S) {
+    cov_mle_cols(cs, m, X, mean, S);
+    double num = 0.0, den = 0.0;
+    for (int b = 0; b < cs; ++b)
+        for (int a = 0; a < cs; ++a) {
+            if (a == b) continue;
+            const double sab = S[a + (size_t)b * cs];
+            double v = 0.0;
+            for (int j = 0; j < m; ++j) {
+                double wj = (X[a + (size_t)j * cs] - mean[a]) * (X[b + (size_t)j * cs] - mean[b]);
+                v += (wj - sab) * (wj - sab);
+            }
+            num += v * ((double)m / ((double)(m - 1) * (m - 1) * (m - 1)));
+            den += sab * sab;
+        }
+    double lam = den > 0 ? num / den : 1.0;
+    lam = jl_clamp(lam, 0.0, 1.0);
+    for (int b = 0; b < cs; ++b)
+        for (int a = 0; a < cs; ++a)
+            if (a != b) S[a + (size_t)b * cs] *= (1 - lam);
+}
+
+/* LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas) [3P, Chen, Wiesel, Eldar & Hero 2010, eqs. (17) and (23)]:
+ * F = tr(S)/p I;  rblw: lambda = ((n-2)/n tr(S^2) + tr(S)^2) / ((n+2)(tr(S^2) - tr(S)^2/p));
+ * oas: lambda = ((1-2/p) tr(S^2) + tr(S)^2) / ((n+1-2/p)(tr(S^2) - tr(S)^2/p)); clamp to [0,1];  S <- (1-lambda) S + lambda F.
+ * UNPINNED. */
+static void cov_common_cols(int cs, int m, const double *X, double *mean, double *S, int oas) {
+    cov_mle_cols(cs, m, X, mean, S);
+    double tr = 0.0, tr2 = 0.0;
+    for (int a = 0; a < cs; ++a) tr += S[a + (size_t)a * cs];
+    for (int b = 0; b < cs; ++b) for (int a = 0; a < cs; ++a) tr2 += S[a + (size_t)b * cs] * S[a + (size_t)b * cs];
+    const double p = cs, n = m;
+    const double dd = tr2 - tr * tr / p;
+    double lam = oas ? ((1 - 2 / p) * tr2 + tr * tr) / ((n + 1 - 2 / p) * dd) : ((n - 2) / n * tr2 + tr * tr) / ((n + 2) * dd);
+    lam = (dd > 0) ? jl_clamp(lam, 0.0, 1.0) : 1.0;
+    const double f = tr / p;
+    for (int b = 0; b < cs; ++b)
+        for (int a = 0; a < cs; ++a)
+            S[a + (size_t)b * cs] = (1 - lam) * S[a + (size_t)b * cs] + ((a == b) ? lam * f : 0.0);
+}
+
 /* StatsBase.mean_and_cov(E, pw::ProbabilityWeights, 2) -- weighted, uncorrected [3P] */
 static void wmean_wcov(int cs, int K, const double *E, const double *w, double *mu, double *S) {
     double wsum = 0.0;
@@ -676,6 +728,9 @@ static void wmean_wcov(int cs, int K, const double *E, const double *w, double *
         mu[r] = s / wsum;
     }
     if (!S) return;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_dense_threads) schedule(dynamic, 1)
+#endif
     for (int b = 0; b < cs; ++b)
         for (int a = 0; a <= b; ++a) {
             double s = 0.0;
@@ -742,6 +797,7 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
 
     const int K = pol->K, cs = pol->cs, kind = pol->kind;
     const int N = (kind == ORC_POL_GMPPI) ? 1 : pol->N;
+    g_dense_threads = pol->nthreads > 0 ? pol->nthreads : 1;
     const double gamma = pol->lambda * (1 - pol->alpha);
     const size_t nn = (size_t)cs * cs;
     double *U_orig = pol->U;                                  /* U_orig = pol.U (same array) */
@@ -811,6 +867,9 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
                     for (int k = 0; k < K; ++k) s += E[r + (size_t)idx[k] * cs];
                     mu[r] = s / K;
                 }
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(g_dense_threads) schedule(dynamic, 1)
+#endif
                 for (int b = 0; b < cs; ++b)
                     for (int a = 0; a <= b; ++a) {
                         double s = 0.0;
@@ -832,6 +891,9 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
                 if (m_elite >= 2 && maxdiff < 10e-3) break;
                 if (kind == ORC_POL_CEMPPI) {                                      /* :464-465 */
                     if (pol->sigma_est == ORC_SIGMA_EST_SS) cov_ss_cols(cs, m_elite, elite, mu, Sig);
+                    else if (pol->sigma_est == ORC_SIGMA_EST_LW) cov_lw_cols(cs, m_elite, elite, mu, Sig);
+                    else if (pol->sigma_est == ORC_SIGMA_EST_RBLW) cov_common_cols(cs, m_elite, elite, mu, Sig, 0);
+                    else if (pol->sigma_est == ORC_SIGMA_EST_OAS) cov_common_cols(cs, m_elite, elite, mu, Sig, 1);
                     else cov_mle_cols(cs, m_elite, elite, mu, Sig);
                     for (int i = 0; i < cs; ++i) Sig[i + (size_t)i * cs] += 10e-9;
                     for (int i = 0; i < cs; ++i) Ucur[i] = Ucur[i] + mu[i];

@@ -92,7 +92,7 @@ void   orc_alias_sample(const double *accept, const int32_t *alias0, int n,
 /* ---- policies -------------------------------------------------------------------------- */
 enum { ORC_POL_MPPI = 0, ORC_POL_GMPPI, ORC_POL_IMPPI, ORC_POL_CEMPPI, ORC_POL_CMAMPPI,
        ORC_POL_MUAISMPPI, ORC_POL_MUSIGMAAISMPPI, ORC_POL_PMCMPPI };
-enum { ORC_SIGMA_EST_MLE = 0, ORC_SIGMA_EST_SS = 1 };
+enum { ORC_SIGMA_EST_MLE = 0, ORC_SIGMA_EST_SS = 1, ORC_SIGMA_EST_LW = 2, ORC_SIGMA_EST_RBLW = 3, ORC_SIGMA_EST_OAS = 4 };
 
 typedef struct {
     int kind, K, T, as, cs, ss, N;

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libmpopis_oracle.so")
 ENV_MOUNTAINCAR, ENV_CAR = 0, 1
 POL = dict(mppi=0, gmppi=1, imppi=2, cemppi=3, cmamppi=4, muaismppi=5, musigmaaismppi=6, pmcmppi=7)
 POL.update({"μaismppi": 5, "μΣaismppi": 6})
-SIGMA_EST = dict(mle=0, ss=1)
+SIGMA_EST = dict(mle=0, ss=1, lw=2, rblw=3, oas=4)
 CP_N, MP_N = 20, 8
 
 

@@ -249,15 +249,16 @@ def test_level3_run_trials_mountaincar(eng_mod, oracle):
     eng.close()
 
 
-def test_level2_cemppi_ss_estimator(eng_mod, oracle, track):
-    """CEMPPI with Σ_est = :ss (the car harness default, src/examples/car_example.jl:66): device shrinkage vs the oracle's
-    restatement of Schäfer-Strimmer (third-party formula, unpinned on both sides)."""
+@pytest.mark.parametrize("est", ["ss", "lw", "rblw", "oas"])
+def test_level2_cemppi_shrinkage_estimators(eng_mod, oracle, track, est):
+    """CEMPPI with the LinearShrinkage estimators (:ss is the car harness default, src/examples/car_example.jl:66): device
+    shrinkage vs the oracle's restatement (third-party CovarianceEstimation.jl formulas, unpinned on both sides)."""
     rng = np.random.default_rng(17)
     K, T, N = 150, 12, 4
     cs = 2 * T
     env = oracle.OracleEnv("car", 1, track=track)
-    pol = oracle.OraclePolicy("cemppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, elite_threshold=0.8, sigma_est="ss")
-    eng = eng_mod.Engine("car", 1, "cemppi", K, T, batch=1, lam=10.0, ais_its=N, elite_threshold=0.8, sigma_est="ss", cov=[0.0625, 0.1], track=track)
+    pol = oracle.OraclePolicy("cemppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, elite_threshold=0.8, sigma_est=est)
+    eng = eng_mod.Engine("car", 1, "cemppi", K, T, batch=1, lam=10.0, ais_its=N, elite_threshold=0.8, sigma_est=est, cov=[0.0625, 0.1], track=track)
     for step in range(2):
         Z = rng.standard_normal((N, K, cs))
         ref = pol(env, Z)
@@ -267,3 +268,46 @@ def test_level2_cemppi_ss_estimator(eng_mod, oracle, track):
         assert np.max(np.abs(got["E"][0].T - ref["E"])) < 1e-8
         assert np.max(np.abs(got["control"][0] - ref["control"])) < 1e-8
     eng.close()
+
+
+def test_cma_posdef_error_matches_reference_behaviour(eng_mod, oracle, track):
+    """:cmamppi 1-car K=4096 H=50: the reference's scalar rank-µ quirk (:588-598) drives Σ indefinite after a few iterations,
+    MvNormal(σ²Σ) throws PosDefException (:551).  Oracle and engine must fail the same way (code -2), not silently continue."""
+    from mpopis_amd._lib import MPOPISError
+    K, T, N = 4096, 50, 10
+    env = oracle.OracleEnv("car", 1, track=track)
+    pol = oracle.OraclePolicy("cmamppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, cma_sigma=0.75, nthreads=8)
+    Z = np.stack([oracle.philox_normals(20240001, 0, n, 2 * T * K).reshape(K, 2 * T) for n in range(N)])
+    r = pol(env, Z)
+    assert r["status"] == -2 and 1 < r["iters_run"] < N
+    eng = eng_mod.Engine("car", 1, "cmamppi", K, T, batch=1, lam=10.0, ais_its=N, cma_sigma=0.75, cov=[0.0625, 0.1], track=track, seed=20240000)
+    with pytest.raises(MPOPISError) as ei:
+        eng.policy_step(None)                              # device Philox stream == the oracle's injected normals
+    assert ei.value.code == -2 and "PosDef" in str(ei.value)
+    eng.close()
+
+
+def test_other_track_through_loader(eng_mod, oracle, tmp_path):
+    """Track(infile; width, sample_factor) with a different centre line (ellipse, 640 points, sample_factor 8, width 9):
+    variable P / lane width reach the kernels through the ABI (car_racing_tracks.jl:14-34)."""
+    import mpopis_amd as M
+    th = np.linspace(0, 2 * np.pi, 640, endpoint=False)
+    pts = np.stack([120 * np.cos(th) - 120, 70 * np.sin(th)], 1)           # passes through the origin heading +y
+    f = tmp_path / "ellipse.csv"
+    np.savetxt(f, pts, delimiter=",")
+    trk = M.Track(str(f), width=9.0, sample_factor=8)
+    assert len(trk.xp) == 80
+    K, T = 128, 30
+    env = M.CarRacingEnv(track=trk)
+    pol = M.GMPPI_Policy(env, num_samples=K, horizon=T, λ=10.0, U0=np.zeros(2), cov_mat=[0.0625, 0.1])
+    otrack = (trk.xp, trk.yp, trk.wp)
+    oenv = oracle.OracleEnv("car", 1, track=otrack)
+    opol = oracle.OraclePolicy("gmppi", oenv, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1])
+    rng = np.random.default_rng(8)
+    for _ in range(4):
+        Z = rng.standard_normal((1, K, 2 * T))
+        a = pol(env, Z=Z); ref = opol(oenv, Z)
+        assert np.max(np.abs(a - ref["control"])) < 1e-8
+        env(a); oenv.step(ref["control"])
+        assert abs(M.reward(env) - oenv.reward()) < 1e-8 * abs(oenv.reward())
+    pol.close()

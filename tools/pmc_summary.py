@@ -40,6 +40,11 @@ if ro:
            "known_read_bytes_per_launch": known_read, "fetch_raw_bytes": fetch_kib * 1024,
            "fetch_calibration_ratio_known_over_raw": known_read / (fetch_kib * 1024) if fetch_kib else None,
            "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+           "valu_insts_per_rollout": (r.get("SQ_INSTS_VALU") or 0.0) / (B * K / 64.0),
+           "fp64_valu_insts_per_rollout": sum((r.get(c) or 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")) / (B * K / 64.0),
+           # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+           "valu_busy_frac": ((r.get("SQ_ACTIVE_INST_VALU") or 0.0) * 4.0) / (((r.get("GRBM_GUI_ACTIVE") or 1.0) / 8.0) * 1024.0),
+           "effective_clock_ghz": ((r.get("GRBM_GUI_ACTIVE") or 0.0) / 8.0) / (r["avg_us"] * 1e3),
            "note": "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md §HBM); 64 trials, K=4096, cs=100"}
     json.dump(out, open("profiles/pmc_rollout.json", "w"), indent=1)
     print(out)
