@@ -98,27 +98,6 @@ MP_HD double fma_v(double a, double b, double c) {
 #endif
 }
 
-// sin/cos for |v| <= 0.25 (Taylor, truncation < 3e-21 relative)
-MP_HD void sincos_small(double v, double* s, double* c) {
-    const double v2 = v * v;
-    double ps = -1.0 / 1307674368000.0;                 // -1/15!
-    ps = fma(ps, v2, 1.0 / 6227020800.0);               // 1/13!
-    ps = fma(ps, v2, -1.0 / 39916800.0);
-    ps = fma(ps, v2, 1.0 / 362880.0);
-    ps = fma(ps, v2, -1.0 / 5040.0);
-    ps = fma(ps, v2, 1.0 / 120.0);
-    ps = fma(ps, v2, -1.0 / 6.0);
-    *s = fma(ps * v2, v, v);
-    double pc = 1.0 / 87178291200.0;                    // 1/14!
-    pc = fma(pc, v2, -1.0 / 479001600.0);
-    pc = fma(pc, v2, 1.0 / 3628800.0);
-    pc = fma(pc, v2, -1.0 / 40320.0);
-    pc = fma(pc, v2, 1.0 / 720.0);
-    pc = fma(pc, v2, -1.0 / 24.0);
-    pc = fma(pc, v2, 0.5);
-    *c = fma(-pc, v2, 1.0);
-}
-
 struct TireK { double fymax, thr, k2, k3; };
 
 MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
@@ -196,14 +175,14 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     double dpsi = r * p.ddt;
     psi += dpsi;
     int nrot = 1;
-    if (fabs(dpsi) > 0.25) {                                   // absurd yaw rates (> 25 rad/s): split the rotation
-        nrot = (int)fmin(ceil(fabs(dpsi) * 4.0), 1024.0);
+    if (fabs(dpsi) > 0.0625) {                                 // |psi_dot| > 6.25 rad/s: split the rotation into <= 1/16 rad pieces
+        nrot = (int)fmin(ceil(fabs(dpsi) * 16.0), 4096.0);
         dpsi = dpsi / nrot;
         psi = fmod(psi, kTwoPi);
     }
     if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;
     double sq, cq;
-    sincos_small(dpsi, &sq, &cq);
+    sincos_tiny(dpsi, &sq, &cq);
     for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
     x += (Vx * cp - Vy * sp) * p.ddt;
     y += (Vx * sp + Vy * cp) * p.ddt;
@@ -254,8 +233,13 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         psi += dpsi;                                                           // :329
         psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);          // :330 atan(sin,cos)
         double sq, cq;
-        if (fabs(dpsi) <= 0.0625) sincos_tiny(dpsi, &sq, &cq); else sincos_small(dpsi, &sq, &cq);   // |r| may exceed 6.25 after the update
+        const bool big = fabs(dpsi) > 0.0625;                  // |r| may exceed 6.25 rad/s after the update: 4 quarter rotations
+        sincos_tiny(big ? 0.25 * dpsi : dpsi, &sq, &cq);       // (|dpsi| <= 0.25 here: |r| was <= 6.25 and |r_dd| δt is bounded by the tyre forces)
         { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        if (big) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        }
         x += (Vx * cp - Vy * sp) * p.ddt;                                      // :331
         y += (Vx * sp + Vy * cp) * p.ddt;                                      // :332
     }
