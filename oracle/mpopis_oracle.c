@@ -797,7 +797,7 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
 
     const int K = pol->K, cs = pol->cs, kind = pol->kind;
     const int N = (kind == ORC_POL_GMPPI) ? 1 : pol->N;
-    g_dense_threads = pol->nthreads > 0 ? pol->nthreads : 1;
+    g_dense_threads = pol->nthreads > 0 ? (pol->nthreads > 32 ? 32 : pol->nthreads) : 1;   /* small loops: more threads only add fork/join cost */
     const double gamma = pol->lambda * (1 - pol->alpha);
     const size_t nn = (size_t)cs * cs;
     double *U_orig = pol->U;                                  /* U_orig = pol.U (same array) */
