@@ -311,3 +311,46 @@ def test_other_track_through_loader(eng_mod, oracle, tmp_path):
         env(a); oenv.step(ref["control"])
         assert abs(M.reward(env) - oenv.reward()) < 1e-8 * abs(oenv.reward())
     pol.close()
+
+
+@pytest.mark.parametrize("kind", ["cemppi", "musigmaaismppi", "pmcmppi", "cmamppi", "muaismppi"])
+def test_level2_mountaincar_default_harness_config(eng_mod, oracle, kind):
+    """simulate_mountaincar's defaults (mountaincar_example.jl:49-70): K=20, H=15 (cs=15, odd), λ=0.1, Σ=[1.5], N=5,
+    λ_ais=0.1 -- odd / tiny sizes through every kernel (potrf n=15, MFMA tiles with padding, bitonic sort n=32, ...)."""
+    rng = np.random.default_rng(31)
+    K, T, N = 20, 15, 5
+    env = oracle.OracleEnv("mountaincar")
+    env.state = [-0.5, 0.0]
+    pol = oracle.OraclePolicy(kind, env, K, T, lam=0.1, U0=[0.0], cov=[1.5], N=N, lam_ais=0.1, elite_threshold=0.8, cma_sigma=0.75)
+    eng = eng_mod.Engine("mountaincar", 0, kind, K, T, batch=2, lam=0.1, ais_its=N, lam_ais=0.1, elite_threshold=0.8, cma_sigma=0.75, cov=[1.5])
+    eng.set_state(np.array([[-0.5, 0.0], [-0.5, 0.0]]))
+    for step in range(3):
+        Z = rng.standard_normal((N, K, T))
+        di = rng.integers(0, K, (N, K)).astype(np.int32); du = rng.random((N, K))
+        ref = pol(env, Z, di, du)
+        got = eng.policy_step(np.stack([Z, Z]), np.stack([di[:N - 1], di[:N - 1]]), np.stack([du[:N - 1], du[:N - 1]]), want_E=True)
+        assert ref["status"] == 0
+        for b in range(2):
+            assert got["iters_run"][b] == ref["iters_run"]
+            assert rel_err(got["cost"][b], ref["cost"]) < 1e-8, (kind, step)
+            assert np.max(np.abs(got["E"][b].T - ref["E"])) < 1e-8
+            assert np.max(np.abs(got["control"][b] - ref["control"])) < 1e-8
+        env.step(ref["control"]); eng.env_step(got["control"])
+    eng.close()
+
+
+def test_level2_odd_sizes_car(eng_mod, oracle, track):
+    """K not a multiple of 16/64, odd K, H giving cs not a multiple of 16."""
+    rng = np.random.default_rng(33)
+    for kind, K, T, N in [("musigmaaismppi", 151, 7, 3), ("cemppi", 77, 9, 3), ("pmcmppi", 101, 5, 3), ("gmppi", 65, 11, 1)]:
+        cs = 2 * T
+        env, pol = make_oracle(oracle, track, kind, 1, K, T, N=N)
+        eng = eng_mod.Engine("car", 1, kind, K, T, batch=1, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, cov=[0.0625, 0.1], track=track)
+        Ne = 1 if kind == "gmppi" else N
+        Z = rng.standard_normal((Ne, K, cs)); di = rng.integers(0, K, (max(Ne - 1, 1), K)).astype(np.int32); du = rng.random((max(Ne - 1, 1), K))
+        ref = pol(env, Z, di, du); got = eng.policy_step(Z[None], di[None], du[None], want_E=True)
+        assert got["iters_run"][0] == ref["iters_run"], kind
+        assert rel_err(got["cost"][0], ref["cost"]) < 1e-8, kind
+        assert np.max(np.abs(got["control"][0] - ref["control"])) < 1e-8, kind
+        assert np.max(np.abs(eng.get_U()[0] - pol.U)) < 1e-8, kind
+        eng.close()
