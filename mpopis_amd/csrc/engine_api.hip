@@ -130,7 +130,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
-    h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 1024 / B)));   // ~2-4 workgroups per CU in the scatter kernel
+    h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));   // ~2-4 workgroups per CU in the scatter kernel
     rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
     if (cfg->policy == MPOPIS_POL_CMAMPPI) {
         rc |= dalloc(h, &h->d_cma_scal, (size_t)B * 8); rc |= dalloc(h, &h->d_cma_vec, (size_t)B * 3 * cs); rc |= dalloc(h, &h->d_sig2, B);
