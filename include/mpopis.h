@@ -36,8 +36,9 @@ extern "C" {
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4 };
 
 /* env kinds: RL.jl MountainCarEnv(continuous=true) + src/examples/mountaincar_example.jl:4-22;
- * CarRacingEnv src/envs/car_racing.jl (num_cars==1) / MultiCarRacingEnv src/envs/multi-car_racing.jl */
-enum { MPOPIS_ENV_MOUNTAINCAR = 0, MPOPIS_ENV_CAR = 1 };
+ * CarRacingEnv src/envs/car_racing.jl (num_cars==1) / MultiCarRacingEnv src/envs/multi-car_racing.jl;
+ * RL.jl CartPoleEnv(continuous=true) + src/examples/cartpole_example.jl:3-6 (state [x,xdot,theta,thetadot]) */
+enum { MPOPIS_ENV_MOUNTAINCAR = 0, MPOPIS_ENV_CAR = 1, MPOPIS_ENV_CARTPOLE = 2 };
 
 /* policy kinds = get_policy symbols, src/examples/example_utils.jl:20-128 */
 enum { MPOPIS_POL_MPPI = 0,            /* :mppi       MPPI_Policy      :107-216 */
@@ -54,9 +55,11 @@ enum { MPOPIS_SIGMA_EST_MLE = 0, MPOPIS_SIGMA_EST_SS = 1, MPOPIS_SIGMA_EST_LW = 
 
 /* Car parameter vector (20 doubles) = CarRacingEnvParams fields in declaration order
  * (src/envs/car_racing.jl:2-21) followed by dt, δt (:33-34).  MountainCar: 8 doubles
- * {min_pos,max_pos,max_speed,goal_pos,goal_velocity,power,gravity,max_steps}. */
+ * {min_pos,max_pos,max_speed,goal_pos,goal_velocity,power,gravity,max_steps}.  CartPole: 11 doubles
+ * {gravity,masscart,masspole,totalmass,halflength,polemasslength,forcemag,dt,thetathreshold,xthreshold,max_steps}. */
 #define MPOPIS_CAR_NPARAMS 20
 #define MPOPIS_MOUNTAINCAR_NPARAMS 8
+#define MPOPIS_CARTPOLE_NPARAMS 11
 
 typedef struct mpopis_handle mpopis_handle;
 

@@ -6,7 +6,7 @@
 # (src/mppi_mpopi_policies.jl:148 vs :186, :240 vs :261): more specific methods of
 #     (pol::AbstractPathIntegralPolicy)(env)         -> mpopis_policy_step
 #     simulate_model(pol, env, E, Σ_inv, U_orig)     -> mpopis_rollout_costs
-# for env::CarRacingEnv / MultiCarRacingEnv / MountainCarEnv.  Every other env type keeps falling
+# for env::CarRacingEnv / MultiCarRacingEnv / MountainCarEnv / CartPoleEnv.  Every other env type keeps falling
 # through to the Julia CPU methods unchanged.  Policy symbols, constructors, `get_policy`,
 # `seed!`, `pol.U`, `pol.Σ`, `pol.logger` are untouched.
 module MPOPISHip
@@ -15,7 +15,7 @@ using MPOPIS
 using MPOPIS: AbstractPathIntegralPolicy, AbstractGMPPI_Policy, MPPI_Policy, GMPPI_Policy, IMPPI_Policy,
               CEMPPI_Policy, CMAMPPI_Policy, μAISMPPI_Policy, μΣAISMPPI_Policy, PMCMPPI_Policy,
               CarRacingEnv, MultiCarRacingEnv
-using ReinforcementLearning: MountainCarEnv
+using ReinforcementLearning: MountainCarEnv, CartPoleEnv
 import MPOPIS: simulate_model
 
 const LIB = get(ENV, "MPOPIS_HIP_LIB", joinpath(@__DIR__, "..", "mpopis_amd", "lib", "libmpopis_hip.so"))
@@ -34,6 +34,7 @@ policy_id(::CEMPPI_Policy) = 3; policy_id(::CMAMPPI_Policy) = 4; policy_id(::μA
 policy_id(::μΣAISMPPI_Policy) = 6; policy_id(::PMCMPPI_Policy) = 7
 
 env_kind(::MountainCarEnv) = (0, 0)
+env_kind(::CartPoleEnv) = (2, 0)
 env_kind(::CarRacingEnv) = (1, 1)
 env_kind(env::MultiCarRacingEnv) = (1, env.N)
 
@@ -69,6 +70,11 @@ function handle(pol, env)
             check(h, ccall((:mpopis_set_env_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), h, p, length(p)))
             check(h, ccall((:mpopis_set_track, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32),
                            h, tr.x′, tr.y′, tr.lane_width′, length(tr.x′)))
+        elseif kind == 2
+            pr = env.params
+            p = Float64[pr.gravity, pr.masscart, pr.masspole, pr.totalmass, pr.halflength, pr.polemasslength, pr.forcemag,
+                        pr.dt, pr.thetathreshold, pr.xthreshold, pr.max_steps]
+            check(h, ccall((:mpopis_set_env_params, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), h, p, length(p)))
         else
             pr = env.params
             p = Float64[pr.min_pos, pr.max_pos, pr.max_speed, pr.goal_pos, pr.goal_velocity, pr.power, pr.gravity, pr.max_steps]
@@ -103,7 +109,7 @@ function hip_policy_call(pol::AbstractPathIntegralPolicy, env)
     return as == 1 ? control : reshape(control, as, 1)        # get_model_controls returns as×1 (utils.jl:55-67)
 end
 
-for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv)
+for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv, :CartPoleEnv)
     @eval (pol::MPPI_Policy)(env::$E) = hip_policy_call(pol, env)
     @eval (pol::AbstractGMPPI_Policy)(env::$E) = hip_policy_call(pol, env)
 end
@@ -121,7 +127,7 @@ function hip_simulate_model(pol::AbstractGMPPI_Policy, env, E::Matrix{Float64}, 
     end
     return cost
 end
-for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv)
+for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv, :CartPoleEnv)
     @eval simulate_model(pol::AbstractGMPPI_Policy, env::$E, E::Matrix{Float64}, Σ_inv::Matrix{Float64}, U_orig::Vector{Float64}) =
         hip_simulate_model(pol, env, E, Σ_inv, U_orig)
 end

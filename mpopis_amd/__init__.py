@@ -6,12 +6,12 @@ MI355X every compute call raises.
 """
 from ._lib import MPOPISError  # noqa: F401
 from .engine import Engine, default_track  # noqa: F401
-from .envs import (CarRacingEnv, CarRacingEnvParams, MultiCarRacingEnv, MountainCarEnv, Track, state, reward,  # noqa: F401
+from .envs import (CarRacingEnv, CarRacingEnvParams, MultiCarRacingEnv, MountainCarEnv, CartPoleEnv, Track, state, reward,  # noqa: F401
                    action_space, is_terminated, within_track, calculate_β, exceed_β)
 from .policies import (MPPI_Policy, GMPPI_Policy, IMPPI_Policy, CEMPPI_Policy, CMAMPPI_Policy, μAISMPPI_Policy,  # noqa: F401
                        μΣAISMPPI_Policy, PMCMPPI_Policy, muAISMPPI_Policy, muSigmaAISMPPI_Policy, get_policy,
                        calculate_trajectory_costs, simulate_model, AbstractGMPPI_Policy, AbstractPathIntegralPolicy)
-from .examples import simulate_car_racing, simulate_mountaincar, quantile_ci, shard_trials  # noqa: F401
+from .examples import simulate_car_racing, simulate_mountaincar, simulate_cartpole, quantile_ci, shard_trials  # noqa: F401
 
 
 def block_diagm(A, rep_number):

@@ -10,7 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmpopis_hip.so")
 
-ENV_MOUNTAINCAR, ENV_CAR = 0, 1
+ENV_MOUNTAINCAR, ENV_CAR, ENV_CARTPOLE = 0, 1, 2
+ENV_IDS = {"mountaincar": ENV_MOUNTAINCAR, "car": ENV_CAR, "cartpole": ENV_CARTPOLE}
 POLICY_IDS = {"mppi": 0, "gmppi": 1, "imppi": 2, "cemppi": 3, "cmamppi": 4,
               "μaismppi": 5, "muaismppi": 5, "μΣaismppi": 6, "musigmaaismppi": 6, "pmcmppi": 7}
 SIGMA_EST_IDS = {"mle": 0, "ss": 1, "lw": 2, "rblw": 3, "oas": 4}

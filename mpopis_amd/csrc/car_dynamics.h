@@ -6,6 +6,7 @@
 //   within_track     == within_track(::Track, pos)         src/envs/car_racing_tracks/car_racing_tracks.jl:68-92
 //   mc_step/mc_reward== MountainCarEnv act!/_step! (RL.jl) + reward override
 //                                                          src/examples/mountaincar_example.jl:4-22
+//   cp_step/cp_reward== CartPoleEnv act!/_step!/reward (RL.jl), src/examples/cartpole_example.jl:3-6
 //
 // How (MI355X-first, not a transcription): one lane integrates one car.  The reference evaluates
 // per Euler sub-step 3 atan2, 2 atan, 2 tan, 3 sincos pairs and 2 sqrt; in FP64 those are ~1000
@@ -347,5 +348,35 @@ MP_HD double mc_reward(const McParams& p, const double* s, int done) {
     rew += done ? 0.0 : -1.0;
     return rew;
 }
+
+// ---- CartPole (continuous) ----------------------------------------------------------------------
+// RL.jl CartPoleEnv(continuous=true) [third-party, recalled: unpinned] driven by the functor of
+// src/examples/cartpole_example.jl:3-6; reward is RL.jl's own (done ? 0 : 1).
+struct CpParams { double gravity, masscart, masspole, totalmass, halflength, polemasslength, forcemag, dt, theta_thr, x_thr; int max_steps; };
+
+MP_HD CpParams make_cp_params(const double* p) {
+    CpParams c;
+    c.gravity = p[0]; c.masscart = p[1]; c.masspole = p[2]; c.totalmass = p[3]; c.halflength = p[4]; c.polemasslength = p[5];
+    c.forcemag = p[6]; c.dt = p[7]; c.theta_thr = p[8]; c.x_thr = p[9]; c.max_steps = (int)p[10];
+    return c;
+}
+
+MP_HD void cp_step(const CpParams& p, double* s, int* t, int* done, double a) {
+    *t += 1;
+    const double force = a * p.forcemag;
+    const double xdot = s[1], theta = s[2], thetadot = s[3];
+    const double costheta = cos(theta), sintheta = sin(theta);
+    const double tmp = (force + p.polemasslength * (thetadot * thetadot) * sintheta) / p.totalmass;
+    const double thetaacc = (p.gravity * sintheta - costheta * tmp) /
+                            (p.halflength * (4.0 / 3.0 - p.masspole * (costheta * costheta) / p.totalmass));
+    const double xacc = tmp - p.polemasslength * thetaacc * costheta / p.totalmass;
+    s[0] += p.dt * xdot;
+    s[1] += p.dt * xacc;
+    s[2] += p.dt * thetadot;
+    s[3] += p.dt * thetaacc;
+    *done = (fabs(s[0]) > p.x_thr || fabs(s[2]) > p.theta_thr || *t > p.max_steps) ? 1 : 0;
+}
+
+MP_HD double cp_reward(int done) { return done ? 0.0 : 1.0; }
 
 }  // namespace mpopis

@@ -30,9 +30,19 @@ struct EnvDesc {
     int ss, as;
     CarParams car;
     McParams mc;
+    CpParams cp;
     Track track;     // device pointers
     double lo[kMaxAs], hi[kMaxAs];
 };
+
+// the two scalar-action classic-control envs share one code path ("simple" envs): ss = 2 or 4, as = 1
+MP_HD void simple_env_step(const EnvDesc& env, double* s, int* t, int* done, double a) {
+    if (env.kind == MPOPIS_ENV_CARTPOLE) cp_step(env.cp, s, t, done, a);
+    else mc_step(env.mc, s, t, done, a);
+}
+MP_HD double simple_env_reward(const EnvDesc& env, const double* s, int done) {
+    return env.kind == MPOPIS_ENV_CARTPOLE ? cp_reward(done) : mc_reward(env.mc, s, done);
+}
 
 // Arguments of the fused rollout kernel (== simulate_model + rollout_model + env step + reward)
 struct RolloutArgs {

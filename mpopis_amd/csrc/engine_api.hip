@@ -86,11 +86,16 @@ static void default_mc_params(double* p) {       // RL.jl MountainCarEnvParams, 
     memcpy(p, v, sizeof v);
 }
 
+static void default_cp_params(double* p) {       // RL.jl CartPoleEnvParams
+    const double v[11] = {9.8, 1.0, 0.1, 1.1, 0.5, 0.05, 10.0, 0.02, 12.0 * 2.0 * M_PI / 360.0, 2.4, 200.0};
+    memcpy(p, v, sizeof v);
+}
+
 int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (!cfg || !out) { g_create_error = "null argument"; return MPOPIS_ERR_ARG; }
     *out = nullptr;
     const bool car = cfg->env_kind == MPOPIS_ENV_CAR;
-    if (!(car || cfg->env_kind == MPOPIS_ENV_MOUNTAINCAR)) { g_create_error = "unknown env kind"; return MPOPIS_ERR_ARG; }
+    if (!(car || cfg->env_kind == MPOPIS_ENV_MOUNTAINCAR || cfg->env_kind == MPOPIS_ENV_CARTPOLE)) { g_create_error = "unknown env kind"; return MPOPIS_ERR_ARG; }
     if (car && (cfg->num_cars < 1 || cfg->num_cars > kMaxCars)) { g_create_error = "num_cars must be 1..4"; return MPOPIS_ERR_ARG; }
     if (cfg->policy < MPOPIS_POL_MPPI || cfg->policy > MPOPIS_POL_PMCMPPI) { g_create_error = "No policy_type of that kind"; return MPOPIS_ERR_ARG; }
     if (cfg->num_samples < 1 || cfg->horizon < 1 || cfg->batch < 1) { g_create_error = "num_samples, horizon, batch must be >= 1"; return MPOPIS_ERR_ARG; }
@@ -103,7 +108,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
     h->as = car ? 2 * cfg->num_cars : 1;
-    h->ss = car ? 8 * cfg->num_cars : 2;
+    h->ss = car ? 8 * cfg->num_cars : (cfg->env_kind == MPOPIS_ENV_CARTPOLE ? 4 : 2);
     h->cs = h->as * h->T;
     h->N = (cfg->policy == MPOPIS_POL_MPPI || cfg->policy == MPOPIS_POL_GMPPI) ? 1 : std::max(1, cfg->ais_its);
     h->gamma = cfg->lambda * (1 - cfg->alpha);
@@ -111,6 +116,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     double p[20];
     default_car_params(p); h->env.car = make_car_params(p);
     default_mc_params(p); h->env.mc = make_mc_params(p);
+    default_cp_params(p); h->env.cp = make_cp_params(p);
     for (int i = 0; i < kMaxAs; ++i) { h->env.lo[i] = -1.0; h->env.hi[i] = 1.0; }
     h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
     const int B = h->B, K = h->K, cs = h->cs;
@@ -178,6 +184,9 @@ int mpopis_set_env_params(mpopis_handle* h, const double* p, int32_t n) {
     if (h->env.kind == MPOPIS_ENV_CAR) {
         if (n != MPOPIS_CAR_NPARAMS) { h->err = "car env expects 20 parameters"; return MPOPIS_ERR_ARG; }
         h->env.car = make_car_params(p);
+    } else if (h->env.kind == MPOPIS_ENV_CARTPOLE) {
+        if (n != MPOPIS_CARTPOLE_NPARAMS) { h->err = "CartPole expects 11 parameters"; return MPOPIS_ERR_ARG; }
+        h->env.cp = make_cp_params(p);
     } else {
         if (n != MPOPIS_MOUNTAINCAR_NPARAMS) { h->err = "MountainCar expects 8 parameters"; return MPOPIS_ERR_ARG; }
         h->env.mc = make_mc_params(p);
@@ -233,7 +242,8 @@ int mpopis_reset(mpopis_handle* h) {
                 s[8 * c + 2] = 90.0 * (M_PI / 180.0);
                 s[8 * c + 3] = 10.0;
             }
-        } else { s[0] = -0.5; s[1] = 0.0; }                     // reference: x ~ U(-0.6,-0.4) from an unseeded RNG
+        } else if (h->env.kind == MPOPIS_ENV_MOUNTAINCAR) { s[0] = -0.5; s[1] = 0.0; }   // reference: x ~ U(-0.6,-0.4) from an unseeded RNG
+        // CartPole: reference draws 0.1*rand(4) - 0.05; deterministic centre = all zeros
     }
     std::vector<int> z(h->B, 0);
     return mpopis_set_state(h, x.data(), z.data(), z.data());

@@ -1,6 +1,7 @@
 // engine_harness.hip -- Level 3: the closed-loop trial harness, resident on the device.
 //   simulate_car_racing trial loop   src/examples/car_example.jl:170-326
 //   simulate_mountaincar trial loop  src/examples/mountaincar_example.jl:125-180
+//   simulate_cartpole trial loop     src/examples/cartpole_example.jl:110-160
 // All B trial slots advance together: policy step -> real env step -> bookkeeping, with no host
 // round trip per MPC step (the host only polls the alive flags every few steps to stop early).
 // A slot that terminates (laps done, > 10 track violations, > 50 β violations, MountainCar done, or
@@ -39,7 +40,7 @@ __global__ void k_harness_update(EnvDesc env, const double* x, const int* done_e
     const double cnt = h[kH_cnt] + 1.0;                                        // :208
     h[kH_cnt] = cnt;
     bool done = false;
-    if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
+    if (env.kind != MPOPIS_ENV_CAR) {
         done = done_env[b] != 0;                                               // env.done from RL.jl _step!
     } else {
         const int NC = env.ncars;

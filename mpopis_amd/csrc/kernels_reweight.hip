@@ -148,14 +148,14 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
     const int b = blockIdx.x, c = threadIdx.x;
     if (alive && !alive[b]) return;
     __shared__ double srew[kMaxCars];
-    if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
+    if (env.kind != MPOPIS_ENV_CAR) {
         if (c == 0) {
             const double a = action[b];
             if (!(a >= env.lo[0] && a <= env.hi[0])) { if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION); }
             int tt = t[b], dd = done[b];
-            mc_step(env.mc, x + (size_t)b * 2, &tt, &dd, a);
+            simple_env_step(env, x + (size_t)b * env.ss, &tt, &dd, a);
             t[b] = tt; done[b] = dd;
-            if (reward) reward[b] = mc_reward(env.mc, x + (size_t)b * 2, dd);
+            if (reward) reward[b] = simple_env_reward(env, x + (size_t)b * env.ss, dd);
         }
         return;
     }
@@ -194,8 +194,8 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
 __global__ void __launch_bounds__(64) k_env_query(EnvDesc env, const double* x, const int* done, double* reward, int* within, double* dist, double* beta) {
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
-    if (env.kind == MPOPIS_ENV_MOUNTAINCAR) {
-        if (reward) reward[b] = mc_reward(env.mc, x + (size_t)b * 2, done[b]);
+    if (env.kind != MPOPIS_ENV_CAR) {
+        if (reward) reward[b] = simple_env_reward(env, x + (size_t)b * env.ss, done[b]);
         if (within) within[b] = 1;
         return;
     }

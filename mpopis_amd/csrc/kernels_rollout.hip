@@ -111,29 +111,35 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_rollout_mountaincar(RolloutArgs a) {
+// MountainCar (ss = 2) and CartPole (ss = 4): scalar action, a handful of flops per step
+template <int SS>
+__global__ void __launch_bounds__(64) k_rollout_simple(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int K = a.K, T = a.T;
     const bool valid = k < K;
     const int kk = valid ? k : K - 1;
-    const McParams& p = a.env.mc;
-    double s[2] = { a.x0[b * 2], a.x0[b * 2 + 1] };
+    double s[SS];
+#pragma unroll
+    for (int i = 0; i < SS; ++i) s[i] = a.x0[b * SS + i];
     int t_env = a.t0 ? a.t0[b] : 0, done = a.done0 ? a.done0[b] : 0;
     const double* Eb = a.E + (size_t)b * a.cs * K + kk;
     const double* Ub = a.Ucur + (size_t)b * a.cs;
     const double* Uo = a.Uorig + (size_t)b * a.cs;
     const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs : nullptr;
-    double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(2 * T) : nullptr;
+    double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(SS * T) : nullptr;
     double cost = 0.0, cc = 0.0;
     for (int t = 0; t < T; ++t) {
         const double v = Ub[t] + Eb[(size_t)t * K];
         if (gv) cc += gv[t] * (v - Uo[t]);
         const double act = clampd(v, a.env.lo[0], a.env.hi[0]);
-        mc_step(p, s, &t_env, &done, act);
-        cost -= mc_reward(p, s, done);
-        if (tr && valid) { tr[t] = s[0]; tr[T + t] = s[1]; }
+        simple_env_step(a.env, s, &t_env, &done, act);
+        cost -= simple_env_reward(a.env, s, done);
+        if (tr && valid) {
+#pragma unroll
+            for (int i = 0; i < SS; ++i) tr[i * T + t] = s[i];
+        }
     }
     if (valid) a.cost[(size_t)b * K + k] = cost + cc;
 }
@@ -156,7 +162,11 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
 
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
-        hipLaunchKernelGGL(k_rollout_mountaincar, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_rollout_simple<2>, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
+        return;
+    }
+    if (a.env.kind == MPOPIS_ENV_CARTPOLE) {
+        hipLaunchKernelGGL(k_rollout_simple<4>, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
         return;
     }
     const int P = a.env.track.P, W = a.env.track.nbrw;

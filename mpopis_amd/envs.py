@@ -5,13 +5,14 @@ reward are the device kernels (mpopis_env_step / mpopis_env_query); nothing is e
   CarRacingEnv        src/envs/car_racing.jl:28-150
   MultiCarRacingEnv   src/envs/multi-car_racing.jl:2-64
   MountainCarEnv      RL.jl MountainCarEnv(continuous=true) + src/examples/mountaincar_example.jl:4-22
+  CartPoleEnv         RL.jl CartPoleEnv(continuous=true) + src/examples/cartpole_example.jl:3-6
   Track               src/envs/car_racing_tracks/car_racing_tracks.jl:2-34
 """
 import math
 import os
 import numpy as np
 
-from .engine import Engine, default_track, _f64
+from .engine import Engine, default_track, BUNDLED_TRACKS, _f64
 from ._lib import MPOPISError, ERR_ARG
 
 
@@ -42,14 +43,15 @@ class CarRacingEnvParams:
 class Track:
     """Track(infile; width=15.0, sample_factor=20): x, y, lane_width and the sub-sampled x′, y′, lane_width′
     (car_racing_tracks.jl:14-34).  `infile=None` is the reference default curve.csv at sample_factor 20,
-    shipped pre-sampled (mpopis_amd/data/curve_sf20.csv)."""
+    shipped pre-sampled (mpopis_amd/data/curve_sf20.csv); the stem of any other reference track file
+    ("curve1".."curve5", "cubic", "cubic1".."cubic5") selects its pre-sampled fixture the same way."""
 
     def __init__(self, infile=None, width=15.0, sample_factor=20):
-        if infile is None:
-            if sample_factor != 20:
-                raise MPOPISError(ERR_ARG, "the bundled default track is pre-sampled at sample_factor=20; pass a CSV path for others")
+        if infile is None or infile in BUNDLED_TRACKS:
+            if sample_factor != 20 or not np.isscalar(width):
+                raise MPOPISError(ERR_ARG, "the bundled tracks are pre-sampled at sample_factor=20 with a constant width; pass a CSV path for others")
             self.x = self.y = self.lane_width = None
-            self.xp, self.yp, self.wp = default_track(width)
+            self.xp, self.yp, self.wp = default_track(width, infile or "curve")
         else:
             d = np.loadtxt(infile, delimiter=",")
             if d.ndim != 2 or d.shape[1] != 2:
@@ -201,6 +203,53 @@ class MountainCarEnv(_EnvBase):
         if state is None:
             x0 = self._x0 if self._x0 is not None else (0.2 * self.rng.random() - 0.6 if self.rng is not None else -0.5)
             self.state = np.array([x0, 0.0])
+        else:
+            self.state = _f64(state).copy()
+        self.t, self.done = 0, False
+        if _make:
+            self._push()
+
+
+class CartPoleEnvParams:
+    """RL.jl CartPoleEnvParams (third-party, recalled)."""
+
+    def __init__(self, gravity=9.8, masscart=1.0, masspole=0.1, halflength=0.5, forcemag=10.0, dt=0.02,
+                 thetathreshold=12 * 2 * math.pi / 360, xthreshold=2.4, max_steps=200):
+        self.gravity, self.masscart, self.masspole, self.halflength = gravity, masscart, masspole, halflength
+        self.totalmass, self.polemasslength = masspole + masscart, masspole * halflength
+        self.forcemag, self.dt, self.thetathreshold, self.xthreshold, self.max_steps = forcemag, dt, thetathreshold, xthreshold, max_steps
+
+    def vector(self):
+        return np.array([self.gravity, self.masscart, self.masspole, self.totalmass, self.halflength, self.polemasslength,
+                         self.forcemag, self.dt, self.thetathreshold, self.xthreshold, float(self.max_steps)])
+
+
+class CartPoleEnv(_EnvBase):
+    """CartPoleEnv(continuous=true, rng=...) driven by the functor of src/examples/cartpole_example.jl:3-6.
+    State [x, xdot, theta, thetadot]; the reference's reset draws 0.1*rand(4) - 0.05 from `rng`
+    (here: from `rng` if given, else the centre of that box, or an explicit `x0`)."""
+
+    def __init__(self, continuous=True, rng=None, x0=None, device=0, **param_kw):
+        if not continuous:
+            raise MPOPISError(ERR_ARG, "only the continuous CartPole of the reference examples is supported")
+        self.params = CartPoleEnvParams(**param_kw)
+        self.rng = rng
+        self.kind, self.ncars, self.as_, self.ss = "cartpole", 0, 1, 4
+        self.track = None
+        self._x0 = x0
+        self._eng_device = device
+        self.reset(_make=False)
+        self._mk_engine(device)
+
+    def _param_vector(self):
+        return self.params.vector()
+
+    def reset(self, state=None, _make=True):
+        if state is None:
+            if self._x0 is not None:
+                self.state = _f64(self._x0).copy()
+            else:
+                self.state = 0.1 * self.rng.random(4) - 0.05 if self.rng is not None else np.zeros(4)
         else:
             self.state = _f64(state).copy()
         self.t, self.done = 0, False

@@ -122,19 +122,17 @@ def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="ce
     return allrec, summ
 
 
-def simulate_mountaincar(num_trials=1, num_steps=200, policy_type="cemppi", num_samples=20, horizon=15, λ=0.1, α=1.0, U0=(0.0,),
+def _simulate_simple(env_kind, ss, num_trials=1, num_steps=200, policy_type="cemppi", num_samples=20, horizon=15, λ=0.1, α=1.0, U0=(0.0,),
                          cov_mat=(1.5,), ais_its=5, λ_ais=0.1, ce_elite_threshold=0.8, ce_Σ_est="mle", cma_σ=0.75,
                          cma_elite_threshold=0.8, seed=None, x0=None, log_runs=True, device=0, quiet=False):
-    """mountaincar_example.jl:49-207; x0: per-trial start positions (the reference draws them unseeded)."""
     pt = str(policy_type).lstrip(":")
     if seed is None:
         seed = int(np.random.default_rng().integers(1, 10 ** 10))
-    eng = Engine("mountaincar", 0, pt, num_samples, horizon, batch=num_trials, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
+    eng = Engine(env_kind, 0, pt, num_samples, horizon, batch=num_trials, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
                  elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
                  cma_sigma=cma_σ, seed=seed, device=device, cov=np.asarray(cov_mat, dtype=np.float64), U0=np.asarray(U0, dtype=np.float64))
     if x0 is not None:
-        x0 = np.asarray(x0, dtype=np.float64).reshape(num_trials)
-        eng.set_state(np.stack([x0, np.zeros(num_trials)], 1))
+        eng.set_state(np.asarray(x0, dtype=np.float64).reshape(num_trials, ss))
     t0 = time.time()
     rec = eng.run_trials(num_steps, 0)
     ex = time.time() - t0
@@ -149,3 +147,36 @@ def simulate_mountaincar(num_trials=1, num_steps=200, policy_type="cemppi", num_
         for name in ("AVE", "STD", "MED", "L95", "U95", "MIN", "MAX"):
             print("Trials %3s: %12.2f : %7.2f: %12.2f : %7.2f" % ((name,) + tuple(summ[name])))
     return rec, summ
+
+
+_SIMPLE_KW = dict(num_trials=1, num_steps=200, policy_type="cemppi", num_samples=20, horizon=15, λ=0.1, α=1.0, U0=(0.0,),
+                  cov_mat=(1.5,), ais_its=5, λ_ais=0.1, ce_elite_threshold=0.8, ce_Σ_est="mle", cma_σ=0.75,
+                  cma_elite_threshold=0.8, seed=None, x0=None, log_runs=True, device=0, quiet=False)
+
+
+def simulate_mountaincar(**kw):
+    """mountaincar_example.jl:49-207 (same keyword arguments and defaults); x0: per-trial start positions
+    (the reference draws x ~ U(-0.6,-0.4) from an unseeded RNG; default here -0.5)."""
+    a = dict(_SIMPLE_KW); _check_kw(a, kw); a.update(kw)
+    if a["x0"] is not None:
+        x = np.asarray(a["x0"], dtype=np.float64).reshape(a["num_trials"])
+        a["x0"] = np.stack([x, np.zeros(a["num_trials"])], 1)
+    return _simulate_simple("mountaincar", 2, **a)
+
+
+def simulate_cartpole(**kw):
+    """cartpole_example.jl:8-190 (same keyword arguments and defaults); x0: (num_trials, 4) start states
+    [x, xdot, theta, thetadot].  The reference draws 0.1*rand(4) - 0.05 from an unseeded MersenneTwister (:111);
+    default here: the same box drawn from numpy's default_rng(seed + k)."""
+    a = dict(_SIMPLE_KW); _check_kw(a, kw); a.update(kw)
+    if a["seed"] is None:
+        a["seed"] = int(np.random.default_rng().integers(1, 10 ** 10))
+    if a["x0"] is None:
+        a["x0"] = np.stack([0.1 * np.random.default_rng(a["seed"] + k + 1).random(4) - 0.05 for k in range(a["num_trials"])])
+    return _simulate_simple("cartpole", 4, **a)
+
+
+def _check_kw(allowed, kw):
+    bad = [k for k in kw if k not in allowed]
+    if bad:
+        raise TypeError("unexpected keyword argument(s): %s" % ", ".join(bad))

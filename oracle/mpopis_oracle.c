@@ -177,6 +177,34 @@ static double mc_reward(const double *p, const double *s, int done) {
 }
 
 /* ======================================================================================
+ * CartPole [3P: ReinforcementLearningEnvironments CartPoleEnv, continuous=true; recalled,
+ * unpinned], functor: src/examples/cartpole_example.jl:3-6; reward = RL.jl's (done ? 0 : 1)
+ * ====================================================================================== */
+void orc_cartpole_default_params(double *p) {
+    p[ORC_XP_GRAVITY] = 9.8; p[ORC_XP_MASSCART] = 1.0; p[ORC_XP_MASSPOLE] = 0.1;
+    p[ORC_XP_TOTALMASS] = p[ORC_XP_MASSPOLE] + p[ORC_XP_MASSCART];
+    p[ORC_XP_HALFLENGTH] = 0.5; p[ORC_XP_POLEMASSLENGTH] = p[ORC_XP_MASSPOLE] * p[ORC_XP_HALFLENGTH];
+    p[ORC_XP_FORCEMAG] = 10.0; p[ORC_XP_DT] = 0.02;
+    p[ORC_XP_THETATHR] = 12 * 2 * M_PI / 360; p[ORC_XP_XTHR] = 2.4; p[ORC_XP_MAXSTEPS] = 200.0;
+}
+
+static void cp_step(const double *p, double *s, int *t, int *done, double a) {
+    *t += 1;
+    double force = a * p[ORC_XP_FORCEMAG];
+    double xdot = s[1], theta = s[2], thetadot = s[3];
+    double costheta = cos(theta), sintheta = sin(theta);
+    double tmp = (force + p[ORC_XP_POLEMASSLENGTH] * (thetadot * thetadot) * sintheta) / p[ORC_XP_TOTALMASS];
+    double thetaacc = (p[ORC_XP_GRAVITY] * sintheta - costheta * tmp) /
+                      (p[ORC_XP_HALFLENGTH] * (4.0 / 3.0 - p[ORC_XP_MASSPOLE] * (costheta * costheta) / p[ORC_XP_TOTALMASS]));
+    double xacc = tmp - p[ORC_XP_POLEMASSLENGTH] * thetaacc * costheta / p[ORC_XP_TOTALMASS];
+    s[0] += p[ORC_XP_DT] * xdot;
+    s[1] += p[ORC_XP_DT] * xacc;
+    s[2] += p[ORC_XP_DT] * thetadot;
+    s[3] += p[ORC_XP_DT] * thetaacc;
+    *done = fabs(s[0]) > p[ORC_XP_XTHR] || fabs(s[2]) > p[ORC_XP_THETATHR] || *t > (int)p[ORC_XP_MAXSTEPS];
+}
+
+/* ======================================================================================
  * env protocol
  * ====================================================================================== */
 void orc_env_init(orc_env *e, int kind, int ncars, const double *params,
@@ -186,6 +214,9 @@ void orc_env_init(orc_env *e, int kind, int ncars, const double *params,
     if (kind == ORC_ENV_CAR) {
         e->ss = 8 * ncars; e->as = 2 * ncars;
         if (params) memcpy(e->params, params, sizeof(double) * ORC_CP_N); else orc_car_default_params(e->params);
+    } else if (kind == ORC_ENV_CARTPOLE) {
+        e->ss = 4; e->as = 1; e->ncars = 0;
+        if (params) memcpy(e->params, params, sizeof(double) * ORC_XP_N); else orc_cartpole_default_params(e->params);
     } else {
         e->ss = 2; e->as = 1; e->ncars = 0;
         if (params) memcpy(e->params, params, sizeof(double) * ORC_MP_N); else orc_mountaincar_default_params(e->params);
@@ -207,9 +238,9 @@ void orc_env_reset(orc_env *e) {
             s[2] = 90.0 * (M_PI / 180.0);
             s[3] = 10.0;
         }
-    } else {
+    } else if (e->kind == ORC_ENV_MOUNTAINCAR) {
         e->state[0] = -0.5; e->state[1] = 0.0;
-    }
+    }   /* CartPole: reference draws 0.1*rand(4)-0.05; here the centre (zeros); callers set state */
 }
 
 void orc_action_bounds(const orc_env *e, double *lo, double *hi) {
@@ -226,6 +257,8 @@ int orc_env_step(orc_env *e, const double *a) {
     if (e->kind == ORC_ENV_CAR) {
         for (int c = 0; c < e->ncars; ++c) orc_car_step(e->params, e->state + 8 * c, a + 2 * c); /* multi :200-207 */
         e->t += 1;
+    } else if (e->kind == ORC_ENV_CARTPOLE) {
+        cp_step(e->params, e->state, &e->t, &e->done, a[0]);
     } else {
         mc_step(e->params, e->state, &e->t, &e->done, a[0]);
     }
@@ -233,6 +266,7 @@ int orc_env_step(orc_env *e, const double *a) {
 }
 
 double orc_env_reward(const orc_env *e) {
+    if (e->kind == ORC_ENV_CARTPOLE) return e->done ? 0.0 : 1.0;
     if (e->kind != ORC_ENV_CAR) return mc_reward(e->params, e->state, e->done);
     if (e->ncars == 1) return orc_car_reward(e->params, e->P, e->tx, e->ty, e->tw, e->state);
     double rew = 0.0;                                                              /* multi-car_racing.jl:145-158 */

@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* ---- environments ------------------------------------------------------------------- */
-enum { ORC_ENV_MOUNTAINCAR = 0, ORC_ENV_CAR = 1 /* ncars>=1; ncars>1 == MultiCarRacingEnv */ };
+enum { ORC_ENV_MOUNTAINCAR = 0, ORC_ENV_CAR = 1 /* ncars>=1; ncars>1 == MultiCarRacingEnv */, ORC_ENV_CARTPOLE = 2 };
 
 /* Car parameter vector, 20 doubles: src/envs/car_racing.jl:2-21,68-93 (+ dt, δt :33-34) */
 enum { ORC_CP_M = 0, ORC_CP_IZZ, ORC_CP_HCM, ORC_CP_LF, ORC_CP_LR, ORC_CP_CD0, ORC_CP_CD1,
@@ -32,6 +32,9 @@ enum { ORC_CP_M = 0, ORC_CP_IZZ, ORC_CP_HCM, ORC_CP_LF, ORC_CP_LR, ORC_CP_CD0, O
 /* MountainCar parameter vector, 8 doubles [3P: RL.jl MountainCarEnvParams, continuous=true] */
 enum { ORC_MP_MINPOS = 0, ORC_MP_MAXPOS, ORC_MP_MAXSPEED, ORC_MP_GOALPOS, ORC_MP_GOALVEL,
        ORC_MP_POWER, ORC_MP_GRAVITY, ORC_MP_MAXSTEPS, ORC_MP_N };
+/* CartPole parameter vector, 11 doubles [3P: RL.jl CartPoleEnvParams] */
+enum { ORC_XP_GRAVITY = 0, ORC_XP_MASSCART, ORC_XP_MASSPOLE, ORC_XP_TOTALMASS, ORC_XP_HALFLENGTH,
+       ORC_XP_POLEMASSLENGTH, ORC_XP_FORCEMAG, ORC_XP_DT, ORC_XP_THETATHR, ORC_XP_XTHR, ORC_XP_MAXSTEPS, ORC_XP_N };
 
 typedef struct {
     int kind;            /* ORC_ENV_* */
@@ -47,6 +50,7 @@ typedef struct {
 
 void   orc_car_default_params(double *p20);
 void   orc_mountaincar_default_params(double *p8);
+void   orc_cartpole_default_params(double *p11);
 void   orc_env_init(orc_env *e, int kind, int ncars, const double *params,
                     int P, const double *tx, const double *ty, const double *tw);
 void   orc_env_reset(orc_env *e);                       /* deterministic resets; MountainCar: x=-0.5 */

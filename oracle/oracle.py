@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmpopis_oracle.so")
 
-ENV_MOUNTAINCAR, ENV_CAR = 0, 1
+ENV_MOUNTAINCAR, ENV_CAR, ENV_CARTPOLE = 0, 1, 2
 POL = dict(mppi=0, gmppi=1, imppi=2, cemppi=3, cmamppi=4, muaismppi=5, musigmaaismppi=6, pmcmppi=7)
 POL.update({"μaismppi": 5, "μΣaismppi": 6})
 SIGMA_EST = dict(mle=0, ss=1, lw=2, rblw=3, oas=4)
@@ -134,13 +134,19 @@ def mountaincar_default_params():
     return p
 
 
+def cartpole_default_params():
+    p = np.zeros(11)
+    lib().orc_cartpole_default_params(_d(p))
+    return p
+
+
 class OracleEnv:
     """Thin holder around orc_env (keeps the borrowed track arrays alive)."""
 
     def __init__(self, kind="car", ncars=1, params=None, track=None):
         self.track = track if track is not None else load_track()
         self.e = Env()
-        k = ENV_CAR if kind == "car" else ENV_MOUNTAINCAR
+        k = {"car": ENV_CAR, "mountaincar": ENV_MOUNTAINCAR, "cartpole": ENV_CARTPOLE}[kind]
         pp = _d(f64(params)) if params is not None else None
         tx, ty, tw = self.track
         lib().orc_env_init(C.byref(self.e), k, ncars, pp, len(tx), _d(tx), _d(ty), _d(tw))

@@ -95,3 +95,24 @@ def test_simulate_car_racing_and_mountaincar(M):
     assert np.array_equal(rec[:, :15], rec2[:, :15])                                    # deterministic for a fixed seed
     recm, _ = M.simulate_mountaincar(num_trials=3, num_steps=200, policy_type=":mppi", x0=[-0.5, -0.45, -0.55], seed=9, quiet=True)
     assert recm.shape == (3, 16) and np.all(recm[:, 1] >= 1)
+
+
+def test_cartpole_env_and_simulate(M, oracle):
+    """CartPoleEnv mirror (cartpole_example.jl:3-6) + simulate_cartpole (same kwargs/defaults as the reference)."""
+    x0 = [0.02, 0.0, -0.03, 0.05]
+    env = M.CartPoleEnv(x0=x0)
+    oenv = oracle.OracleEnv("cartpole"); oenv.state = x0
+    pol = M.get_policy(":cemppi", env, 20, 15, 0.1, 1.0, [0.0], [1.5], False, 5, 0.1, 0.8, ":mle", 0.75, 0.8)
+    for _ in range(5):
+        act = pol(env)
+        assert act.shape == (1,) and -1.0 <= act[0] <= 1.0
+        env(act); oenv.step(act)
+        assert np.max(np.abs(M.state(env) - oenv.state)) < 1e-13
+        assert M.reward(env) == oenv.reward() and bool(M.is_terminated(env)) == bool(oenv.e.done)
+    pol.close()
+    rec, summ = M.simulate_cartpole(num_trials=3, num_steps=60, seed=11, quiet=True)
+    assert rec.shape == (3, 16) and np.all(rec[:, 1] >= 1) and np.all(rec[:, 15] == 0)
+    rec2, _ = M.simulate_cartpole(num_trials=3, num_steps=60, seed=11, quiet=True)
+    assert np.array_equal(rec[:, :15], rec2[:, :15])
+    with pytest.raises(TypeError):
+        M.simulate_cartpole(num_trails=1)

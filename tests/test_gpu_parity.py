@@ -249,6 +249,78 @@ def test_level3_run_trials_mountaincar(eng_mod, oracle):
     eng.close()
 
 
+def test_level1_cartpole_with_logger(eng_mod, oracle):
+    """CartPole: simulate_model + trajectory logger, ss = 4."""
+    rng = np.random.default_rng(31)
+    K, T = 200, 15
+    x0 = np.array([0.02, -0.1, 0.03, 0.2])
+    env = oracle.OracleEnv("cartpole"); env.state = x0
+    eng = eng_mod.Engine("cartpole", 0, "gmppi", K, T, batch=1, lam=0.1, cov=[1.5], log_trajectories=True)
+    E = rng.standard_normal((1, K, T)) * 1.2
+    U = rng.uniform(-0.5, 0.5, T)
+    got = eng.rollout_costs(U[None], E, x0=x0[None])
+    pol = oracle.OraclePolicy("gmppi", env, K, T, lam=0.1, U0=[0.0], cov=[1.5])
+    ref, tr_ref = pol.simulate_model(U, E[0].T, log=True)
+    assert np.array_equal(got[0], ref)                       # costs are small integers: exact
+    tr = eng.get_trajectories()[0]
+    assert rel_err(tr, tr_ref) < 1e-12
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["mppi", "cemppi", "musigmaaismppi", "pmcmppi", "cmamppi"])
+def test_level2_cartpole(eng_mod, oracle, kind):
+    """pol(env) on CartPole with the simulate_cartpole defaults (cartpole_example.jl:35-50), closed loop for 4 MPC steps."""
+    rng = np.random.default_rng(33)
+    K, T, N = 20, 15, 5
+    x0 = np.array([0.03, 0.0, -0.04, 0.1])
+    env = oracle.OracleEnv("cartpole"); env.state = x0
+    pol = oracle.OraclePolicy(kind, env, K, T, lam=0.1, U0=[0.0], cov=[1.5], N=N, lam_ais=0.1, elite_threshold=0.8, cma_sigma=0.75)
+    eng = eng_mod.Engine("cartpole", 0, kind, K, T, batch=1, lam=0.1, ais_its=N, lam_ais=0.1, elite_threshold=0.8, cma_sigma=0.75, cov=[1.5])
+    eng.set_state(x0[None])
+    Neff = 1 if kind == "mppi" else N
+    for step in range(4):
+        if kind == "mppi":
+            Z = rng.standard_normal((T, K, 1)); Zo, Ze = Z, Z[None]
+        else:
+            Z = rng.standard_normal((Neff, K, T)); Zo, Ze = Z, Z[None]
+        ri = rng.integers(0, K, (max(1, Neff - 1), K)).astype(np.int32); ru = rng.random((max(1, Neff - 1), K))
+        ref = pol(env, Zo, ri, ru)
+        if ref["status"]:
+            from mpopis_amd._lib import MPOPISError
+            with pytest.raises(MPOPISError) as ei:
+                eng.policy_step(Ze, ri[None], ru[None])
+            assert ei.value.code == ref["status"]
+            break
+        got = eng.policy_step(Ze, ri[None], ru[None])
+        assert got["iters_run"][0] == ref["iters_run"]
+        assert np.array_equal(got["cost"][0], ref["cost"])
+        assert np.max(np.abs(got["weights"][0] - ref["weights"])) < 1e-12
+        assert abs(got["control"][0, 0] - ref["control"][0]) < 1e-9
+        env.step(ref["control"])
+        r = eng.env_step(ref["control"][None])               # same action on both sides keeps the loops aligned
+        assert r[0] == env.reward()
+        x, t, done = eng.get_state()
+        assert np.max(np.abs(x[0] - env.state)) < 1e-13 and t[0] == env.e.t and done[0] == env.e.done
+        eng.set_U(pol.U[None])
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["mppi", "cemppi"])
+def test_level3_run_trials_cartpole(eng_mod, oracle, kind):
+    K, T, N = 20, 15, 5
+    x0s = np.array([[0.01, 0.02, -0.03, 0.04], [-0.04, 0.0, 0.045, -0.02]])
+    eng = eng_mod.Engine("cartpole", 0, kind, K, T, batch=2, lam=0.1, ais_its=N, elite_threshold=0.8, cov=[1.5], seed=21)
+    eng.set_state(x0s)
+    rec = eng.run_trials(num_steps=200, laps=0)
+    for b in range(2):
+        env = oracle.OracleEnv("cartpole"); env.state = x0s[b]
+        pol = oracle.OraclePolicy(kind, env, K, T, lam=0.1, U0=[0.0], cov=[1.5], N=N, elite_threshold=0.8)
+        r = pol.run_trial(env, 21 + b + 1, num_steps=200)
+        assert rec[b, 15] == r["status"]
+        assert rec[b, 1] == r["steps"] and rec[b, 0] == r["rew"], (rec[b], r)
+    eng.close()
+
+
 @pytest.mark.parametrize("est", ["ss", "lw", "rblw", "oas"])
 def test_level2_cemppi_shrinkage_estimators(eng_mod, oracle, track, est):
     """CEMPPI with the LinearShrinkage estimators (:ss is the car harness default, src/examples/car_example.jl:66): device
@@ -311,6 +383,43 @@ def test_other_track_through_loader(eng_mod, oracle, tmp_path):
         env(a); oenv.step(ref["control"])
         assert abs(M.reward(env) - oenv.reward()) < 1e-8 * abs(oenv.reward())
     pol.close()
+
+
+@pytest.mark.parametrize("name", ["curve1", "curve2", "curve3", "curve4", "curve5", "cubic", "cubic1", "cubic2", "cubic3", "cubic4", "cubic5"])
+def test_bundled_reference_tracks(eng_mod, oracle, name):
+    """The reference's other centre-line files (src/envs/car_racing_tracks/*.csv) at sample_factor 20:
+    few points (P = 12..26 < the neighbour-table width for some), open and closed shapes.  Rollout costs (anchored
+    nearest-point search) and reward / within_track / dist of the resident env (full search) against the oracle."""
+    import mpopis_amd as M
+    trk = M.Track(name, width=4.0)              # narrow lane: a good share of the 3 s rollouts leaves it
+    tx, ty, tw = trk.arrays()
+    P = len(tx)
+    assert 12 <= P <= 26
+    rng = np.random.default_rng(P)
+    K, T = 256, 30
+    # start on the centre line at point 1, heading along the local direction, 10 m/s
+    psi = np.arctan2(ty[2] - ty[1], tx[2] - tx[1])
+    x0 = np.array([tx[1], ty[1], psi, 10.0, 0.0, 0.0, 0.0, 0.0])
+    oenv = oracle.OracleEnv("car", 1, track=(tx, ty, tw)); oenv.state = x0
+    opol = oracle.OraclePolicy("gmppi", oenv, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1])
+    eng = eng_mod.Engine("car", 1, "gmppi", K, T, batch=1, lam=10.0, cov=[0.0625, 0.1], track=(tx, ty, tw))
+    E = rng.standard_normal((1, K, 2 * T)) * np.tile([0.5, 0.6], T)          # wide steering noise: many rollouts leave the lane
+    got = eng.rollout_costs(np.zeros((1, 2 * T)), E, x0=x0[None])
+    ref = opol.simulate_model(np.zeros(2 * T), E[0].T)
+    assert (ref > 1e6).sum() > 0 and (ref < 1e6).sum() > 0                   # both sides of the lane penalty are exercised
+    assert rel_err(got[0], ref) < RTOL
+    # resident-env queries at scattered positions around the track (inside and outside the lane)
+    for _ in range(40):
+        i = rng.integers(0, P)
+        pos = np.array([tx[i], ty[i]]) + rng.uniform(-30, 30, 2)
+        st = x0.copy(); st[:2] = pos
+        oenv.state = st
+        eng.set_state(st[None])
+        rew, within, dist, beta = eng.env_query()
+        w_ref, d_ref = oracle.within_track((tx, ty, tw), pos)
+        assert bool(within[0]) == bool(w_ref) and abs(dist[0, 0] - d_ref) <= 1e-12 * max(1.0, d_ref)
+        assert abs(rew[0] - oenv.reward()) <= 1e-12 * abs(oenv.reward())
+    eng.close()
 
 
 @pytest.mark.parametrize("kind", ["cemppi", "musigmaaismppi", "pmcmppi", "cmamppi", "muaismppi"])

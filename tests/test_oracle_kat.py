@@ -195,6 +195,72 @@ def test_mountaincar_step_and_reward(oracle):
     assert env.step([1.5]) == -3                                                     # not in action space
 
 
+def _cartpole_step_py(s, t, a):
+    """independent scalar re-evaluation of RL.jl's CartPoleEnv _step! (recalled; see oracle header [3P])"""
+    x, xd, th, thd = s
+    force = a * 10.0
+    tmp = (force + 0.05 * thd ** 2 * math.sin(th)) / 1.1
+    thacc = (9.8 * math.sin(th) - math.cos(th) * tmp) / (0.5 * (4 / 3 - 0.1 * math.cos(th) ** 2 / 1.1))
+    xacc = tmp - 0.05 * thacc * math.cos(th) / 1.1
+    s2 = [x + 0.02 * xd, xd + 0.02 * xacc, th + 0.02 * thd, thd + 0.02 * thacc]
+    t += 1
+    done = abs(s2[0]) > 2.4 or abs(s2[2]) > 12 * 2 * math.pi / 360 or t > 200
+    return s2, t, done
+
+
+def test_cartpole_step_and_reward(oracle):
+    env = oracle.OracleEnv("cartpole")
+    assert env.ss == 4 and env.as_ == 1 and np.all(env.state == 0.0)
+    p = oracle.cartpole_default_params()
+    assert p[3] == 1.1 and p[5] == 0.05 and p[8] == pytest.approx(0.20943951023931953, rel=1e-15)
+    assert env.step([1.0]) == 0
+    # from rest at the origin with full push: tmp = 10/1.1, thetaacc = -tmp / (0.5 (4/3 - 0.1/1.1))
+    tmp = 10 / 1.1
+    thacc = -tmp / (0.5 * (4 / 3 - 0.1 / 1.1))
+    xacc = tmp - 0.05 * thacc / 1.1
+    np.testing.assert_allclose(env.state, [0.0, 0.02 * xacc, 0.0, 0.02 * thacc], rtol=RTOL)
+    assert env.e.done == 0 and env.reward() == 1.0
+    # a generic state against the scalar re-evaluation, 30 steps of bang-bang control
+    s, t = [0.01, -0.02, 0.03, 0.04], 0
+    env.reset(); env.state = s
+    for i in range(30):
+        a = 1.0 if i % 3 else -0.7
+        env.step([a]); s, t, done = _cartpole_step_py(s, t, a)
+        np.testing.assert_allclose(env.state, s, rtol=1e-13, atol=1e-16)
+        assert env.e.t == t and bool(env.e.done) == done and env.reward() == (0.0 if done else 1.0)
+    env.reset(); env.state = [2.39, 1.0, 0.0, 0.0]                                  # x leaves +-2.4
+    env.step([0.0]); assert env.e.done == 1 and env.reward() == 0.0
+    env.reset(); env.state = [0.0, 0.0, 0.2, 1.0]                                   # theta leaves +-12 deg
+    env.step([0.0]); assert env.e.done == 1
+    env.reset()                                                                     # t > max_steps (200) -> done at step 201
+    for i in range(201):
+        env.state = [0.0, 0.0, 0.0, 0.0]; env.step([0.0])
+        assert env.e.done == (1 if i == 200 else 0)
+    assert env.step([1.5]) == -3
+
+
+def test_cemppi_cartpole_defaults(oracle):
+    """simulate_cartpole's defaults (cartpole_example.jl:35-50): :cemppi K=20 H=15 lambda=0.1 Sigma=[1.5] N=5 elite 0.8, :mle."""
+    env = oracle.OracleEnv("cartpole"); env.state = [0.01, 0.0, -0.02, 0.0]
+    K, T, N = 20, 15, 5
+    pol = oracle.OraclePolicy("cemppi", env, K, T, lam=0.1, U0=[0.0], cov=[1.5], N=N, elite_threshold=0.8)
+    Z = np.random.default_rng(4).standard_normal((N, K, T))
+    r = pol(env, Z)
+    assert r["status"] == 0 and 1 <= r["iters_run"] <= N
+    # costs are minus the number of not-done steps: integers in [-T, 0]
+    assert np.all(r["cost"] == np.round(r["cost"])) and r["cost"].min() >= -T and r["cost"].max() <= 0
+    # independent re-evaluation of the final-iteration costs from the returned E (E holds V - U_orig, U_orig = 0)
+    E = r["E"]
+    for k in range(K):
+        s, t, c = [0.01, 0.0, -0.02, 0.0], 0, 0.0
+        for tt in range(T):
+            s, t, done = _cartpole_step_py(s, t, min(max(E[tt, k], -1.0), 1.0))
+            c -= 0.0 if done else 1.0
+        assert c == r["cost"][k]
+    r2 = pol.run_trial(env, 7, num_steps=50)
+    assert r2["status"] == 0 and r2["steps"] >= 1
+
+
 def test_get_model_controls_and_rollout(oracle, track):
     env = oracle.OracleEnv("car", 1, track=track)
     pol = oracle.OraclePolicy("gmppi", env, 3, 4, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1])
