@@ -87,6 +87,23 @@ MP_HD double fast_rcp(double v) {
 #endif
 }
 
+// sqrt for arguments that are >= 0 and not huge: v_rsq_f64 seed (2^-24) + one coupled Newton step + one residual
+// correction = 1 ulp max error (measured, tools/rcp_acc.hip), without the denormal-range rescaling of the library
+// sqrt (8 VALU ops instead of 18).  The 1e-300 bias keeps an exact 0 finite (result 1e-150) and is absorbed by any
+// normal-range argument; NaN propagates.
+MP_HD double fast_sqrt(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += 1e-300;
+    const double y = __builtin_amdgcn_rsq(v);
+    double g = v * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    return fma(fma(-g, g, v), h, g);
+#else
+    return sqrt(v);
+#endif
+}
+
 // fma with all three operands in VGPRs.  hipcc turns `p = fma(p, x, C)` with a loop-invariant constant C into
 // `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, x` (one extra VALU op per Horner step); the explicit VOP3 form needs no copy.
 MP_HD double fma_v(double a, double b, double c) {
@@ -103,7 +120,7 @@ struct TireK { double fymax, thr, k2, k3; };
 
 MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
     TireK k;
-    k.fymax = sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));           // :253
+    k.fymax = fast_sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));      // :253
     const double rf = fast_rcp(k.fymax), rc = 1.0 / Ca;        // rc: Ca is wave-uniform
     k.thr = 3 * k.fymax * rc;                                  // tan of the switch angle :255
     k.k2 = ((Ca * Ca) * (1.0 / 3.0)) * rf;                     // C^2/(3 fy_max)
@@ -151,6 +168,7 @@ MP_HD double tire_poly(double ta, double Ca, const TireK& k) {
 //   front: alpha_f = atan2(yf,Vx) - delta is the angle of q = R(-delta)(Vx,yf) up to a 2pi wrap that can
 //          only occur when |alpha_f| > pi (saturated anyway).  Linear branch <=> q.x > 0 and |q.y/q.x| < T;
 //          saturated sign = sign(q.y) if q.x > 0 else sign(yf) (|alpha_f| >= pi/2 > |delta|).
+template <bool PSI>
 MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, double cd,
                                double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp) {
     const double sg = jl_sign(Vx);
@@ -174,14 +192,14 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;
     r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;
     double dpsi = r * p.ddt;
-    psi += dpsi;
+    if (PSI) psi += dpsi;
     int nrot = 1;
     if (fabs(dpsi) > 0.0625) {                                 // |psi_dot| > 6.25 rad/s: split the rotation into <= 1/16 rad pieces
         nrot = (int)fmin(ceil(fabs(dpsi) * 16.0), 4096.0);
         dpsi = dpsi / nrot;
-        psi = fmod(psi, kTwoPi);
+        if (PSI) psi = fmod(psi, kTwoPi);
     }
-    if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi;
+    if (PSI) { if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi; }
     double sq, cq;
     sincos_tiny(dpsi, &sq, &cq);
     for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
@@ -193,14 +211,18 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
 // Transcendental-free (requires |delta| < pi/2, guaranteed by delta_max and actions in [-1,1]).
 // Hot path (Vx > 0, front slip in the forward half plane, |psi_dot| <= 6.25 rad/s): branch-free,
 // tyre constants hoisted, one shared reciprocal; everything else goes through car_substep_general.
+// PSI = false drops the bookkeeping of the heading ANGLE (accumulate + wrap, :329-330): the dynamics and the reward
+// only consume sin/cos(psi), which are carried by rotation, so rollouts that do not log trajectories never need it
+// (c.psi is then left untouched = stale).
+template <bool PSI = true>
 MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1) {
-    double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r, delta = c.delta;
+    double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r;
     double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
     {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation)
         const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
         sp *= fp; cp *= fp; sd *= fd; cd *= fd;
     }
-    const double tgt = a0 * p.dmax - delta;
+    const double tgt = a0 * p.dmax - c.delta;
     const double rate = fmin(fabs(tgt) * p.inv_dt, p.ddotmax) * jl_sign(tgt);  // :295-296
     const double dd = rate * p.ddt;
     const double pedal = a1;                                                   // :297
@@ -208,43 +230,53 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0);
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
+    const double fxr0 = fxr - p.CD0;                           // rear drive force minus the constant part of the drag (:308)
     const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157
     for (int it = 0; it < p.nsub; ++it) {
-        delta += dd;                                                           // :301
-        { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }
+        { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
         if (!(Vx > 0.0 && xq > 0.0 && fabs(r) <= 6.25)) {                      // cold: stopped / sliding / spinning / NaN
-            car_substep_general(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
+            car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
             continue;
         }
         const double rinv = fast_rcp(Vx * xq);
         const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
-        const double fyr = (fabs(tar) < kr.thr) ? tire_poly(tar, p.Car, kr) : -copysign(kr.fymax, yr);
-        const double fyf = (fabs(taf) < kf.thr) ? tire_poly(taf, p.Caf, kf) : -copysign(kf.fymax, yq);
-        const double fx_aero = fma(p.CD1, Vx, p.CD0);                          // :308
-        const double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);          // :322
-        const double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;                   // :323
-        const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;         // :324
-        r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;               // :326-328
+        // the brush model is C1 at the switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259): evaluating
+        // the cubic at the clamped tangent is the same function (the cubic at +-thr is -+fy_max up to rounding)
+        const double fyr = tire_poly(fmax(fmin(tar, kr.thr), -kr.thr), p.Car, kr);
+        const double fyf = tire_poly(fmax(fmin(taf, kf.thr), -kf.thr), p.Caf, kf);
+        const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral component
+        const double rdd = p.inv_Izz * fma(p.lf, flat, -(p.lr * fyr));                          // :322
+        const double Vyd = fma(p.inv_m, flat + fyr, -(r * Vx));                                 // :323
+        const double Vxd = fma(p.inv_m, fma(fxf, cd, -(fyf * sd)) + fma(-p.CD1, Vx, fxr0), r * Vy);   // :324 (+ drag :308)
+        r = fma(rdd, p.ddt, r); Vx = fma(Vxd, p.ddt, Vx); Vy = fma(Vyd, p.ddt, Vy);            // :326-328
         const double dpsi = r * p.ddt;
-        psi += dpsi;                                                           // :329
-        psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);          // :330 atan(sin,cos)
-        double sq, cq;
-        const bool big = fabs(dpsi) > 0.0625;                  // |r| may exceed 6.25 rad/s after the update: 4 quarter rotations
-        sincos_tiny(big ? 0.25 * dpsi : dpsi, &sq, &cq);       // (|dpsi| <= 0.25 here: |r| was <= 6.25 and |r_dd| δt is bounded by the tyre forces)
-        { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-        if (big) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        if (PSI) {
+            psi += dpsi;                                                       // :329
+            psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);      // :330 atan(sin,cos)
         }
-        x += (Vx * cp - Vy * sp) * p.ddt;                                      // :331
-        y += (Vx * sp + Vy * cp) * p.ddt;                                      // :332
+        double sq, cq;
+        sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/16 ...
+        const double sp0 = sp, cp0 = cp;
+        { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        if (fabs(dpsi) > 0.0625) {                             // ... |r| may exceed 6.25 rad/s after the update: redo as 4 quarter
+            sincos_tiny(0.25 * dpsi, &sq, &cq);                // rotations (|dpsi| <= 0.25: |r| was <= 6.25 and |r_dd| δt is bounded)
+            sp = sp0; cp = cp0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        }
+        x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                            // :331
+        y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                               // :332
     }
-    c.x = x; c.y = y; c.psi = psi; c.Vx = Vx; c.Vy = Vy; c.r = r; c.delta = delta; c.pedal = pedal;
+    // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
+    double delta = c.delta;
+    if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
+    else delta = fma((double)p.nsub, dd, delta);
+    c.x = x; c.y = y; if (PSI) c.psi = psi; c.Vx = Vx; c.Vy = Vy; c.r = r; c.delta = delta; c.pedal = pedal;
     c.sp = sp; c.cp = cp; c.sd = sd; c.cd = cd;
 }
 
@@ -264,7 +296,7 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
         const int S = tk.nbrw + 1;
         mi = a0;
         best = fma(tk.y[a0], m2y, fma(tk.x[a0], m2x, tk.n2[a0]));
-        const double bound = 2.0 * sqrt(fmax(best + fma(px, px, py * py), 0.0)) + 1e-6;
+        const double bound = 2.0 * fast_sqrt(fmax(best + fma(px, px, py * py), 0.0)) + 1e-6;
         bool closed = false;
         for (int c = 1; c < tk.nbrw; ++c) {
             if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
@@ -289,13 +321,16 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
     const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
     const double p1x = tk.x[mi], p1y = tk.y[mi];
     const double ax = tk.x[im] - px, ay = tk.y[im] - py, bx = tk.x[ip] - px, by = tk.y[ip] - py;
-    const double dm = sqrt(ax * ax + ay * ay), dp = sqrt(bx * bx + by * by);   // :77-78
-    const bool prev = dm <= dp;                                                // :79
+    // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone); only when the squares agree
+    // to a few ulp could rounding of the square roots collapse an inequality into the reference's tie -> literal form
+    const double dm2 = fma(ax, ax, ay * ay), dp2 = fma(bx, bx, by * by);
+    bool prev = dm2 <= dp2;
+    if (fabs(dm2 - dp2) <= 1e-15 * dp2) prev = sqrt(ax * ax + ay * ay) <= sqrt(bx * bx + by * by);
     const double p2x = prev ? tk.x[im] : tk.x[ip], p2y = prev ? tk.y[im] : tk.y[ip];
     const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
-    const double t = (ux * vx + uy * vy) / (vx * vx + vy * vy);                // :87
+    const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
     const double ex = (p1x + t * vx) - px, ey = (p1y + t * vy) - py;           // :88-89
-    const double dist = sqrt(ex * ex + ey * ey);
+    const double dist = fast_sqrt(ex * ex + ey * ey);
     *dist_out = dist;
     return dist < tk.w[mi];                                                    // :90
 }
@@ -314,7 +349,7 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
     if (!within) rew += -1000000.0;
     if (exceed_beta(p, Vx, Vy)) rew += -5000.0;                                // exceed_β :184-189
     rew += -dist;
-    rew += 2.0 * sqrt(Vx * Vx + Vy * Vy);
+    rew += 2.0 * fast_sqrt(Vx * Vx + Vy * Vy);
     return rew;
 }
 

@@ -19,7 +19,8 @@
 namespace mpopis {
 
 // NC cars x SPB sample-waves per workgroup: the SPB*64 samples of a workgroup share one LDS copy of the track tables
-template <int NC, int SPB>
+// LOG: the trajectory logger is on (a.traj != nullptr) -- only then is the heading angle psi itself tracked
+template <int NC, int SPB, bool LOG>
 __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     const double* Uo = a.Uorig + (size_t)b * a.cs + 2 * c;
     const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs + 2 * c : nullptr;
     const double lo0 = a.env.lo[2 * c], hi0 = a.env.hi[2 * c], lo1 = a.env.lo[2 * c + 1], hi1 = a.env.hi[2 * c + 1];
-    double* tr = a.traj ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
+    double* tr = LOG ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
 
     __shared__ double sh_xy[2][SPB][NC][2][64];
     __shared__ double sh_cost[SPB][NC][64];
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
         if (t + 1 < T) { e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K]; }
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
         const double a0 = clampd(v0, lo0, hi0), a1 = clampd(v1, lo1, hi1);     // get_model_controls
-        car_action_step(p, s, a0, a1);
+        car_action_step<LOG>(p, s, a0, a1);
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
         if (NC > 1) {                                                          // multi-car_racing.jl:145-158
             const int buf = t & 1;
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
             }
         }
         cost -= rew;                                                           // utils.jl:138
-        if (tr && valid) {                                                     // trajectories[k][t, :] utils.jl:140
+        if (LOG && valid) {                                                    // trajectories[k][t, :] utils.jl:140
             double s8[8];
             car_state_to8(s, s8);
 #pragma unroll
@@ -174,17 +175,19 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 sample-waves share the LDS tables
     const bool wide = a.K >= 1024;
     const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B), g2((a.K + 127) / 128, a.B);
+#define MPOPIS_LAUNCH_CAR(NC, SPB, GRID, BLOCK)                                                        \
+    do {                                                                                               \
+        if (a.traj) hipLaunchKernelGGL((k_rollout_car<NC, SPB, true>), GRID, dim3(BLOCK), lds, st, a);  \
+        else        hipLaunchKernelGGL((k_rollout_car<NC, SPB, false>), GRID, dim3(BLOCK), lds, st, a); \
+    } while (0)
     switch (a.env.ncars) {
-        case 1: if (wide) hipLaunchKernelGGL((k_rollout_car<1, 4>), g4, dim3(256), lds, st, a);
-                else      hipLaunchKernelGGL((k_rollout_car<1, 1>), g1, dim3(64), lds, st, a);
-                break;
-        case 2: if (wide) hipLaunchKernelGGL((k_rollout_car<2, 2>), g2, dim3(256), lds, st, a);
-                else      hipLaunchKernelGGL((k_rollout_car<2, 1>), g1, dim3(128), lds, st, a);
-                break;
-        case 3: hipLaunchKernelGGL((k_rollout_car<3, 1>), g1, dim3(192), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((k_rollout_car<4, 1>), g1, dim3(256), lds, st, a); break;
+        case 1: if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64); break;
+        case 2: if (wide) MPOPIS_LAUNCH_CAR(2, 2, g2, 256); else MPOPIS_LAUNCH_CAR(2, 1, g1, 128); break;
+        case 3: MPOPIS_LAUNCH_CAR(3, 1, g1, 192); break;
+        case 4: MPOPIS_LAUNCH_CAR(4, 1, g1, 256); break;
         default: break;
     }
+#undef MPOPIS_LAUNCH_CAR
 }
 
 }  // namespace mpopis
