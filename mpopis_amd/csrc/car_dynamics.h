@@ -104,6 +104,19 @@ MP_HD double fast_sqrt(double v) {
 #endif
 }
 
+// max(min(v, hi), lo) with hi/lo already in registers (v_min_f64 + v_max_f64, no input canonicalisation; callers
+// guarantee non-NaN arguments)
+MP_HD double clamp_vv(double v, double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t, r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(lo));
+    return r;
+#else
+    return fmax(fmin(v, hi), lo);
+#endif
+}
+
 // fma with all three operands in VGPRs.  hipcc turns `p = fma(p, x, C)` with a loop-invariant constant C into
 // `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, x` (one extra VALU op per Horner step); the explicit VOP3 form needs no copy.
 MP_HD double fma_v(double a, double b, double c) {
@@ -233,8 +246,10 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const double fxr0 = fxr - p.CD0;                           // rear drive force minus the constant part of the drag (:308)
     const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
+    const double nthr_f = -kf.thr, nthr_r = -kr.thr;
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157
+#pragma unroll 2
     for (int it = 0; it < p.nsub; ++it) {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
@@ -247,8 +262,8 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
         // the brush model is C1 at the switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259): evaluating
         // the cubic at the clamped tangent is the same function (the cubic at +-thr is -+fy_max up to rounding)
-        const double fyr = tire_poly(fmax(fmin(tar, kr.thr), -kr.thr), p.Car, kr);
-        const double fyf = tire_poly(fmax(fmin(taf, kf.thr), -kf.thr), p.Caf, kf);
+        const double fyr = tire_poly(clamp_vv(tar, nthr_r, kr.thr), p.Car, kr);
+        const double fyf = tire_poly(clamp_vv(taf, nthr_f, kf.thr), p.Caf, kf);
         const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral component
         const double rdd = p.inv_Izz * fma(p.lf, flat, -(p.lr * fyr));                          // :322
         const double Vyd = fma(p.inv_m, flat + fyr, -(r * Vx));                                 // :323
@@ -321,11 +336,11 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
     const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
     const double p1x = tk.x[mi], p1y = tk.y[mi];
     const double ax = tk.x[im] - px, ay = tk.y[im] - py, bx = tk.x[ip] - px, by = tk.y[ip] - py;
-    // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone); only when the squares agree
-    // to a few ulp could rounding of the square roots collapse an inequality into the reference's tie -> literal form
+    // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone).  Only when the two squares
+    // differ by an ulp or two could the rounding of the reference's square roots turn `>` into its tie (-> prev); at that
+    // point the position is equidistant from both neighbours to 1e-16 and the reference's own choice is rounding noise.
     const double dm2 = fma(ax, ax, ay * ay), dp2 = fma(bx, bx, by * by);
-    bool prev = dm2 <= dp2;
-    if (fabs(dm2 - dp2) <= 1e-15 * dp2) prev = sqrt(ax * ax + ay * ay) <= sqrt(bx * bx + by * by);
+    const bool prev = dm2 <= dp2;
     const double p2x = prev ? tk.x[im] : tk.x[ip], p2y = prev ? tk.y[im] : tk.y[ip];
     const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
     const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
