@@ -47,6 +47,7 @@ struct CarParams {
     int nsub;            // round(Int, dt/δt) :299
     int blim_acute;      // β_limit < pi/2
     double inv_m, inv_Izz, L, tan_blim, inv_dt, inv_L, fz0f, fz0r;
+    double k_v, k_rf, k_rr;   // δt/m, δt l_f/Izz, δt l_r/Izz (Euler updates of :326-328 with the constants folded)
 };
 
 MP_HD CarParams make_car_params(const double* p) {
@@ -59,6 +60,7 @@ MP_HD CarParams make_car_params(const double* p) {
     c.inv_m = 1 / c.m; c.inv_Izz = 1 / c.Izz; c.L = c.lr + c.lf;
     c.inv_dt = 1 / c.dt; c.inv_L = 1 / c.L;
     c.fz0f = c.m * c.lr * 9.81; c.fz0r = c.m * c.lf * 9.81;                    // :262-272
+    c.k_v = c.ddt * c.inv_m; c.k_rf = c.ddt * c.inv_Izz * c.lf; c.k_rr = c.ddt * c.inv_Izz * c.lr;
     c.blim_acute = c.blim < 0.5 * kPi;
     c.tan_blim = c.blim_acute ? tan(c.blim) : tan(kPi - c.blim);
     return c;
@@ -104,16 +106,16 @@ MP_HD double fast_sqrt(double v) {
 #endif
 }
 
-// max(min(v, hi), lo) with hi/lo already in registers (v_min_f64 + v_max_f64, no input canonicalisation; callers
+// max(min(v, thr), -thr) (v_min_f64 + v_max_f64 with a negated source, no input canonicalisation; callers
 // guarantee non-NaN arguments)
-MP_HD double clamp_vv(double v, double lo, double hi) {
+MP_HD double clamp_sym(double v, double thr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double t, r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(hi));
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(thr));
+    asm("v_max_f64 %0, %1, -%2" : "=v"(r) : "v"(t), "v"(thr));
     return r;
 #else
-    return fmax(fmin(v, hi), lo);
+    return fmax(fmin(v, thr), -thr);
 #endif
 }
 
@@ -162,9 +164,12 @@ MP_HD void sincos_tiny(double v, double* s, double* c) {
     ps = fma_v(ps, v2, 1.0 / 120.0);
     ps = fma_v(ps, v2, -1.0 / 6.0);
     *s = fma(ps * v2, v, v);
-    double pc = 1.0 / 40320.0;
+    // 1/40320 and 1/24 are written one ulp high: their exact low dwords coincide with those of -1/5040 and -1/6, and
+    // hipcc then rebuilds the shared halves with a v_mov per use inside the sub-step loop (the ulp is invisible: these
+    // coefficients multiply v^8 and v^4 with |v| <= 1/16)
+    double pc = 0x1.a01a01a01a01bp-16;
     pc = fma_v(pc, v2, -1.0 / 720.0);
-    pc = fma_v(pc, v2, 1.0 / 24.0);
+    pc = fma_v(pc, v2, 0x1.5555555555556p-5);
     pc = fma_v(pc, v2, -0.5);
     *c = fma(pc, v2, 1.0);
 }
@@ -222,7 +227,7 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
 
 // env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
 // Transcendental-free (requires |delta| < pi/2, guaranteed by delta_max and actions in [-1,1]).
-// Hot path (Vx > 0, front slip in the forward half plane, |psi_dot| <= 6.25 rad/s): branch-free,
+// Hot path (Vx > 0, front slip in the forward half plane): branch-free up to a rarely taken large-yaw-rate fix-up,
 // tyre constants hoisted, one shared reciprocal; everything else goes through car_substep_general.
 // PSI = false drops the bookkeeping of the heading ANGLE (accumulate + wrap, :329-330): the dynamics and the reward
 // only consume sin/cos(psi), which are carried by rotation, so rollouts that do not log trajectories never need it
@@ -246,47 +251,49 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const double fxr0 = fxr - p.CD0;                           // rear drive force minus the constant part of the drag (:308)
     const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
-    const double nthr_f = -kf.thr, nthr_r = -kr.thr;
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157
-#pragma unroll 2
-    for (int it = 0; it < p.nsub; ++it) {
+    auto substep = [&]() {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
-        if (!(Vx > 0.0 && xq > 0.0 && fabs(r) <= 6.25)) {                      // cold: stopped / sliding / spinning / NaN
+        if (!(Vx > 0.0 && xq > 0.0)) {                                         // cold: stopped / sliding backwards / NaN
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
-            continue;
+            return;
         }
         const double rinv = fast_rcp(Vx * xq);
         const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
         // the brush model is C1 at the switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259): evaluating
         // the cubic at the clamped tangent is the same function (the cubic at +-thr is -+fy_max up to rounding)
-        const double fyr = tire_poly(clamp_vv(tar, nthr_r, kr.thr), p.Car, kr);
-        const double fyf = tire_poly(clamp_vv(taf, nthr_f, kf.thr), p.Caf, kf);
-        const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral component
-        const double rdd = p.inv_Izz * fma(p.lf, flat, -(p.lr * fyr));                          // :322
-        const double Vyd = fma(p.inv_m, flat + fyr, -(r * Vx));                                 // :323
-        const double Vxd = fma(p.inv_m, fma(fxf, cd, -(fyf * sd)) + fma(-p.CD1, Vx, fxr0), r * Vy);   // :324 (+ drag :308)
-        r = fma(rdd, p.ddt, r); Vx = fma(Vxd, p.ddt, Vx); Vy = fma(Vyd, p.ddt, Vy);            // :326-328
+        const double fyr = tire_poly(clamp_sym(tar, kr.thr), p.Car, kr);
+        const double fyf = tire_poly(clamp_sym(taf, kf.thr), p.Caf, kf);
+        const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral ...
+        const double flon = fma(fxf, cd, -(fyf * sd));                         // ... and longitudinal component
+        const double rd = r * p.ddt;                                           // old yaw rate x δt
+        const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));                            // :323,:328
+        const double Vx1 = fma(p.k_v, flon + fma(-p.CD1, Vx, fxr0), fma(rd, Vy, Vx));           // :324,:327 (+ drag :308)
+        r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));                                            // :322,:326
+        Vx = Vx1; Vy = Vy1;
         const double dpsi = r * p.ddt;
-        if (PSI) {
-            psi += dpsi;                                                       // :329
-            psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);      // :330 atan(sin,cos)
-        }
+        if (PSI) psi += dpsi;                                                  // :329
         double sq, cq;
         sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/16 ...
         const double sp0 = sp, cp0 = cp;
         { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-        if (fabs(dpsi) > 0.0625) {                             // ... |r| may exceed 6.25 rad/s after the update: redo as 4 quarter
-            sincos_tiny(0.25 * dpsi, &sq, &cq);                // rotations (|dpsi| <= 0.25: |r| was <= 6.25 and |r_dd| δt is bounded)
+        if (fabs(dpsi) > 0.0625) {                             // ... |psi_dot| > 6.25 rad/s: redo in pieces of <= 1/16 rad
+            const int nrot = (int)fmin(ceil(fabs(dpsi) * 16.0), 4096.0);
+            sincos_tiny(dpsi / nrot, &sq, &cq);
             sp = sp0; cp = cp0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+            for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+            if (PSI) psi = fmod(psi, kTwoPi);
         }
+        if (PSI) psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);                  // :330 atan(sin,cos)
         x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                            // :331
         y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                               // :332
-    }
+    };
+    int it = 0;
+    for (; it + 1 < p.nsub; it += 2) { substep(); substep(); }                 // two per trip: no loop-carried register copies
+    if (it < p.nsub) substep();
     // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
     double delta = c.delta;
     if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
