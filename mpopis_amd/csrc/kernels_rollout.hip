@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
         const double v0 = Ub[t * as] + e0, v1 = Ub[t * as + 1] + e1;           // V = pol.U + E[:,k]  :271
         if (t + 1 < T) { e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K]; }
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
-        const double a0 = clampd(v0, lo0, hi0), a1 = clampd(v1, lo1, hi1);     // get_model_controls
+        const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
         car_action_step<LOG>(p, s, a0, a1);
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
         if (NC > 1) {                                                          // multi-car_racing.jl:145-158

@@ -55,7 +55,17 @@ int main(int argc, char** argv) {
         double err = 0; for (int i = 0; i < cs; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k <= j; ++k) v += L[i + (size_t)k * cs] * L[j + (size_t)k * cs]; err = fmax(err, fabs(v - A[i + (size_t)j * cs])); }
         printf("   potrf max |LL'-A| = %.3e\n", err);
     }
-    printf("trmm_mfma        %8.1f us  (%.1f TF)\n", 0.0f, 0.0f);
+    {
+        uint64_t* dseeds; CK(hipMalloc(&dseeds, B * 8));
+        std::vector<uint64_t> hs(B); for (int b = 0; b < B; ++b) hs[b] = 20240000 + b;
+        CK(hipMemcpy(dseeds, hs.data(), B * 8, hipMemcpyHostToDevice));
+        float ts = timeit([&] { launch_sample_normal(dE, B, cs, K, 2, 0, dseeds, 3u, 1u, nullptr, dact, s); }, 20, s);
+        printf("sample_normal    %8.1f us  (%.2f Gnormals/s)\n", ts, (double)B * cs * K / (ts * 1e-6) / 1e9);
+        CK(hipMemcpy(dL, A.data(), nn * B * 8, hipMemcpyHostToDevice));
+        launch_potrf(dA, nn, dL, B, cs, nullptr, dstatus, dact, s);
+        float tf = timeit([&] { launch_sample_trmm_fused(dL, nn, dE, B, cs, K, dseeds, 3u, 1u, dact, s); }, 20, s);
+        printf("sample+trmm fused%8.1f us\n", tf);
+    }
     float t = timeit([&] { launch_trmm_LZ_mfma(dL, nn, dZ, dE, B, cs, K, dact, s); }, 20, s);
     printf("trmm_mfma        %8.1f us  (%.1f TF half-counted)\n", t, (double)B * cs * cs * K / (t * 1e-6) / 1e12);
     t = timeit([&] { launch_wcov_mfma(dZ, dw, nullptr, K, dmu, dS, dpart, B, cs, K, ksplit, 0.0, 1e-8, dact, s, nullptr); }, 20, s);
