@@ -107,7 +107,8 @@ void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, i
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
-                      const double* rscale = nullptr);
+                      const double* rscale = nullptr, double* mu_out = nullptr);
+bool wcov_mfma_can_emit_mean(int cs);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);
 void launch_fill_f64(double* p, double v, size_t n, hipStream_t s);

@@ -181,7 +181,7 @@ template <int KC, bool SQ>
 __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
                                                            const double* __restrict__ mu, const double* __restrict__ rscale,
                                                            double* __restrict__ part, int cs, int K, int m,
-                                                           int ksplit, int npairs, const int* active) {
+                                                           int ksplit, int npairs, const int* active, int aug) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
@@ -241,7 +241,9 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
             const int row = sr0 + u * kRowStep;
             double v = xreg[u];
             if (SQ) { v = (v - mureg[u]) * rsreg[u]; v *= v; }
-            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : 0.0;                      // centred, zero padded
+            // zero padded; aug: the first padding row carries ones, so row cs of the scatter is Σ_k w_k x_k (the weighted
+            // mean comes out of the same pass over X and the separate E·w kernel is not needed)
+            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : ((aug && row == cs && kin_cur) ? 1.0 : 0.0);
         }
         if (sr0 == 0) ws[skk] = kin_cur ? wreg : 0.0;
         __syncthreads();
@@ -270,11 +272,13 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
 // Σ_k w_k, or m for unweighted gathered columns)
 __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
-                                                          const double* __restrict__ mu_corr, double wtot_unweighted) {
+                                                          const double* __restrict__ mu_corr, double wtot_unweighted,
+                                                          double* __restrict__ mu_aug) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
     __shared__ double sden, swtot;
+    __shared__ double smu[32];
     if (w) {                                                    // Σ_k w_k (ProbabilityWeights)
         double sacc = 0.0;
         for (int k = threadIdx.x; k < K; k += 256) sacc += w[(size_t)b * K + k];
@@ -292,11 +296,26 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     const int e = threadIdx.x;                                  // e = lane*4 + r  (lane 0..63, r 0..3)
     const int lane = e >> 2, r = e & 3;
     const int ia = ta * 16 + (lane >> 4) + 4 * r, ibb = tb * 16 + (lane & 15);
+    if (mu_aug) {
+        // μ_j = (row cs of the augmented scatter)_j / Σw: element (cs % 16, j % 16) of tile pair (cs / 16, j / 16)
+        if (threadIdx.x < 32) {
+            const int t = (threadIdx.x < 16) ? ta : tb, jl = threadIdx.x & 15;
+            const int taug = cs >> 4, il = cs & 15;
+            const int qa = taug * (taug + 1) / 2 + t, ea = (((il & 3) * 16 + jl) << 2) + (il >> 2);
+            double m = 0.0;
+            for (int sp = 0; sp < ksplit; ++sp) m += part[(((size_t)b * ksplit + sp) * npairs + qa) * 256 + ea];
+            m = m / swtot;
+            smu[threadIdx.x] = m;
+            if (ta == taug && threadIdx.x >= 16 && tb * 16 + jl < cs) mu_aug[(size_t)b * cs + tb * 16 + jl] = m;
+        }
+        __syncthreads();
+    }
     if (ia >= cs || ibb >= cs) return;
     if (ta == tb && ibb > ia) return;
     double v = 0.0;
     for (int sp = 0; sp < ksplit; ++sp) v += part[(((size_t)b * ksplit + sp) * npairs + q) * 256 + e];
-    if (mu_corr) v = fma(-mu_corr[(size_t)b * cs + ia] * swtot, mu_corr[(size_t)b * cs + ibb], v);
+    if (mu_aug) v = fma(-smu[ia - ta * 16] * swtot, smu[16 + ibb - tb * 16], v);
+    else if (mu_corr) v = fma(-mu_corr[(size_t)b * cs + ia] * swtot, mu_corr[(size_t)b * cs + ibb], v);
     v = v * inv;
     if (ia == ibb) v += ridge;
     Sg[(size_t)b * cs * cs + (size_t)ia + (size_t)ibb * cs] = v;
@@ -392,8 +411,11 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
     const int nt = (cs + 15) / 16;
     return (size_t)B * ksplit * (nt * (nt + 1) / 2) * 256;
 }
+bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale) {
+                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
+                      double* mu_out) {
+    const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
     const size_t lds = ((size_t)nt * 16 * (kc + 2) + kc) * sizeof(double);
@@ -407,14 +429,14 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     }
     const dim3 grid(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B);
     if (rscale) {
-        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
-        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
     } else {
-        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
-        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active);
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
-                       rscale ? (const double*)nullptr : mu, (double)m);
+                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr);
 }
 
 }  // namespace mpopis

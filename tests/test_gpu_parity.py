@@ -135,6 +135,30 @@ def test_level2_policy_step(eng_mod, oracle, track, kind, ncars):
     eng.close()
 
 
+@pytest.mark.parametrize("T", [8, 24, 7])
+def test_level2_musigma_tile_aligned_and_ragged_cs(eng_mod, oracle, track, T):
+    """μΣ-AIS moments: cs = 16 / 48 (multiples of the 16-row MFMA tile: no padding row, separate weighted-mean kernel) and
+    cs = 14 (ragged: mean emitted by the scatter kernel's ones row) must agree with the oracle alike."""
+    rng = np.random.default_rng(T)
+    B, K, N, kind = 2, 320, 4, "musigmaaismppi"
+    cs = 2 * T
+    eng = eng_mod.Engine("car", 1, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track)
+    envs, pols = zip(*[make_oracle(oracle, track, kind, 1, K, T, N=N) for _ in range(B)])
+    eng.set_state(np.stack([e.state for e in envs]))
+    for step in range(2):
+        Z = rng.standard_normal((B, N, K, cs))
+        got = eng.policy_step(Z, want_E=True)
+        U_dev = eng.get_U()
+        for b in range(B):
+            ref = pols[b](envs[b], Z[b])
+            assert ref["status"] == 0 and got["iters_run"][b] == ref["iters_run"]
+            assert rel_err(got["cost"][b], ref["cost"]) < RTOL
+            assert np.max(np.abs(got["E"][b].T - ref["E"])) < 1e-8
+            assert np.max(np.abs(got["control"][b] - ref["control"])) < 1e-8
+            assert np.max(np.abs(U_dev[b] - pols[b].U)) < 1e-8
+    eng.close()
+
+
 def test_level2_mppi_mountaincar_config1(eng_mod, oracle):
     """BASELINE config 1 (plumbing): MountainCar :mppi K=20 H=15 λ=0.1 Σ=[1.5]."""
     rng = np.random.default_rng(2)
