@@ -47,61 +47,103 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
     double* W; int ldw, m;
     if (LDS) { W = smem; ldw = npad; m = npad; } else { W = Lb; ldw = n; m = n; }
     if (tid == 0) failed = 0;
-    // copy in: batches of 8 unconditional (clamped) loads in flight per thread, select afterwards
-    for (int e0 = tid; e0 < m * m; e0 += NTHR * 8) {
-        double av[8];
+    // copy in the lower triangle only (the upper triangle of W is never consumed): columns c and m-1-c together hold m+1
+    // entries, so the triangle is the (m/2) x (m+1) rectangle e -> (c, t); batches of 8 unconditional (clamped) loads in
+    // flight per thread, select afterwards.  (m even: npad is a multiple of 16; the global-memory variant keeps m = n.)
+    if (LDS) {
+        const int tot = (m / 2) * (m + 1);
+        for (int e0 = tid; e0 < tot; e0 += NTHR * 8) {
+            double av[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = min(e0 + u * NTHR, m * m - 1), i = e % m, j = e / m;
-            av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * NTHR, tot - 1), c = e / (m + 1), t = e - c * (m + 1);
+                const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * NTHR;
+                if (e < tot) {
+                    const int c = e / (m + 1), t = e - c * (m + 1);
+                    const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                    W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
+                }
+            }
         }
+    } else {
+        for (int e0 = tid; e0 < m * m; e0 += NTHR * 8) {
+            double av[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * NTHR;
-            if (e < m * m) {
-                const int i = e % m, j = e / m;
-                double v;
-                if (i < n && j < n) v = (i >= j) ? sc * av[u] : 0.0;
-                else v = (i == j) ? 1.0 : 0.0;
-                W[(size_t)i + (size_t)j * ldw] = v;
+            for (int u = 0; u < 8; ++u) {
+                const int e = min(e0 + u * NTHR, m * m - 1), i = e % m, j = e / m;
+                av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * NTHR;
+                if (e < m * m) {
+                    const int i = e % m, j = e / m;
+                    W[(size_t)i + (size_t)j * ldw] = (i >= j) ? sc * av[u] : 0.0;
+                }
             }
         }
     }
     __syncthreads();
 
     const int li = lane & 15, lk = lane >> 4;
-    for (int j0 = 0; j0 < m; j0 += kNB) {
-        const int nb = min(kNB, m - j0);
-        // (1) diagonal block, wave 0, lane = row (rows/cols >= nb behave as identity)
-        if (wv == 0) {
-            double d[kNB];
-            const bool rowok = lane < nb;
+    constexpr int NW = NTHR / 64;
+    // (1) diagonal block, one wave, lane = row (rows/cols >= nb behave as identity)
+    auto factor_diag = [&](int j0, int nb) {
+        double d[kNB];
+        const bool rowok = lane < nb;
 #pragma unroll
-            for (int c = 0; c < kNB; ++c) d[c] = (rowok && c < nb) ? W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] : ((lane == c) ? 1.0 : 0.0);
-            bool bad = false;
+        for (int c = 0; c < kNB; ++c) d[c] = (rowok && c < nb) ? W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] : ((lane == c) ? 1.0 : 0.0);
+        bool bad = false;
 #pragma unroll
-            for (int jj = 0; jj < kNB; ++jj) {
-                const double piv = bcast_lane(d[jj], jj);
-                if (!(piv > 0.0)) bad = true;
-                double rs = __builtin_amdgcn_rsq(piv);              // v_rsq_f64 seed + 2 Newton steps (full precision)
-                rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-                rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-                const double ljj = piv * rs;                        // sqrt(piv)
-                if (lane == jj) { d[jj] = ljj; rdiag[jj] = rs; } else if (lane > jj) d[jj] = d[jj] * rs;
+        for (int jj = 0; jj < kNB; ++jj) {
+            const double piv = bcast_lane(d[jj], jj);
+            if (!(piv > 0.0)) bad = true;
+            double rs = __builtin_amdgcn_rsq(piv);              // v_rsq_f64 seed + 2 Newton steps (full precision)
+            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+            const double ljj = piv * rs;                        // sqrt(piv)
+            if (lane == jj) { d[jj] = ljj; rdiag[jj] = rs; } else if (lane > jj) d[jj] = d[jj] * rs;
 #pragma unroll
-                for (int c = jj + 1; c < kNB; ++c) {
-                    const double lcj = bcast_lane(d[jj], c);
-                    if (lane >= c) d[c] = fma(-d[jj], lcj, d[c]);
-                }
+            for (int c = jj + 1; c < kNB; ++c) {
+                const double lcj = bcast_lane(d[jj], c);
+                if (lane >= c) d[c] = fma(-d[jj], lcj, d[c]);
             }
-            if (rowok) {
-#pragma unroll
-                for (int c = 0; c < kNB; ++c) if (c < nb && c <= lane) W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] = d[c];
-            }
-            if (bad && lane == 0) failed = 1;
         }
-        __syncthreads();
+        if (rowok) {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) if (c < nb && c <= lane) W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] = d[c];
+        }
+        if (bad && lane == 0) failed = 1;
+    };
+    // (3) one 16x16 tile of the rank-16 trailing update on the matrix cores: pair q -> tile (t1 + ta, t1 + tb), ta >= tb
+    auto trail_pair = [&](int j0, int t1, int q) {
+        int ta = 0, qq = q;
+        while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
+        const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ra = r0 + li, rb = c0 + li, col = j0 + kk * 4 + lk;
+            const double av = (ra < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0;
+            const double bv = (rb < m) ? W[(size_t)rb + (size_t)col * ldw] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r0 + li, c = c0 + lk + 4 * r;                               // D'[c - c0][i - r0]
+            if (i < m && c < m && i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
+        }
+    };
+    if (wv == 0) factor_diag(0, min(kNB, m));
+    __syncthreads();
+    for (int j0 = 0; j0 < m; j0 += kNB) {
         if (failed) break;
+        const int nb = min(kNB, m - j0);
         const int i1 = j0 + nb;              // first row below the panel
         // (2) panel solve: row i of L21 = A21[i,:] * L11^-T
         for (int i = i1 + tid; i < m; i += NTHR) {
@@ -121,28 +163,19 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
             for (int c = 0; c < kNB; ++c) if (c < nb) W[(size_t)i + (size_t)(j0 + c) * ldw] = x[c];
         }
         __syncthreads();
-        // (3) trailing update on the matrix cores: tile (ti, tc), ti >= tc, rows/cols beyond the panel
+        // (3) trailing update with one panel of look-ahead: wave 0 updates the next diagonal tile first and factors it
+        // right away, while the other waves update the remaining tiles (rows/cols beyond the panel)
         const int t1 = i1 / 16;                                  // i1 is a multiple of 16 except after the last (partial) panel
         const int ntile = (m + 15) / 16 - t1;
         if (nb == kNB && ntile > 0) {
             const int npair = ntile * (ntile + 1) / 2;
-            for (int q = wv; q < npair; q += NTHR / 64) {
-                int ta = 0, qq = q;
-                while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
-                const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
-                v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int ra = r0 + li, rb = c0 + li, col = j0 + kk * 4 + lk;
-                    const double av = (ra < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0;
-                    const double bv = (rb < m) ? W[(size_t)rb + (size_t)col * ldw] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = r0 + li, c = c0 + lk + 4 * r;                               // D'[c - c0][i - r0]
-                    if (i < m && c < m && i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
-                }
+            if (wv == 0) {
+                trail_pair(j0, t1, 0);
+                if (!LDS) __threadfence_block();
+                factor_diag(i1, min(kNB, m - i1));
+                if (NW == 1) for (int q = 1; q < npair; ++q) trail_pair(j0, t1, q);
+            } else {
+                for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q);
             }
         }
         __syncthreads();
@@ -162,8 +195,8 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
-        hipLaunchKernelGGL((k_potrf<true, 256>), dim3(B), dim3(256), bytes, s, A, Astride, L, n, npad, scale, status, active);
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        hipLaunchKernelGGL((k_potrf<true, 512>), dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
         hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), 0, s, A, Astride, L, n, n, scale, status, active);
     }

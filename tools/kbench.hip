@@ -40,7 +40,8 @@ int main(int argc, char** argv) {
     double *dA, *dL, *dZ, *dE, *dw, *dmu, *dS, *dpart; int *dstatus, *dact;
     CK(hipMalloc(&dA, nn * B * 8)); CK(hipMalloc(&dL, nn * B * 8)); CK(hipMalloc(&dZ, Z.size() * 8)); CK(hipMalloc(&dE, Z.size() * 8));
     CK(hipMalloc(&dw, w.size() * 8)); CK(hipMalloc(&dmu, mu.size() * 8)); CK(hipMalloc(&dS, nn * B * 8));
-    const int ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));
+    const int ksplit = getenv("KSPLIT") ? atoi(getenv("KSPLIT")) : std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));
+    printf("ksplit=%d\n", ksplit);
     CK(hipMalloc(&dpart, wcov_mfma_workspace_doubles(B, cs, ksplit) * 8));
     CK(hipMalloc(&dstatus, B * 4)); CK(hipMalloc(&dact, B * 4));
     CK(hipMemcpy(dA, A.data(), nn * B * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dZ, Z.data(), Z.size() * 8, hipMemcpyHostToDevice));
