@@ -160,7 +160,7 @@ def main():
             "mpc_steps_per_s": B * world * args.steps / dt,
             "config": {"workload": "Car-Racing 1-car :μΣaismppi K=4096 H=50 N=10 λ=10 λ_ais=20, %d independent trials per GPU (BASELINE configs[4])" % B,
                        "trials_per_gpu": B, "rollouts_per_step": int(B * N_AIS * K), "parallelism": "trials sharded x%d, RCCL gather of summary stats" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1, 4>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1, 4, false>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
                          "binding_resource": "FP64 VALU issue (not HBM, not MFMA); valu_busy_frac from the PMC pass in profiles/",

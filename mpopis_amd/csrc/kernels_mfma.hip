@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = (cs + 15) / 16, rows_pad = nt * 16;
-    constexpr int S = KC + 2;                                   // LDS row stride (doubles): conflict-free MFMA operand reads
+    constexpr int S = KC + 1;                                   // LDS row stride (doubles); odd strides measured best (tools/kbench)
     constexpr int kMaxLd = (KC == 64) ? 28 : 32;                // staged elements per thread and chunk (cs <= 112 resp. 512 rows)
     constexpr int kRowStep = 256 / KC;
     double* Xs = smem;                                          // [rows_pad][S]
@@ -418,7 +418,7 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
-    const size_t lds = ((size_t)nt * 16 * (kc + 2) + kc) * sizeof(double);
+    const size_t lds = ((size_t)nt * 16 * (kc + 1) + kc) * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
