@@ -158,6 +158,11 @@ int  mpopis_get_trajectories(mpopis_handle *h, double *out);
  *   [0] rew [1] steps [2] rew/step [3..6] lap_t[1..4] [7] mean_v [8] max_v [9] mean_β [10] max_β
  *   [11] β_viol [12] T_viol [13] C_viol [14] rollouts executed [15] status            (:144-155,287-302) */
 #define MPOPIS_RECORD_LEN 16
+/* state_x_sigma, state_y_sigma, state_ψ_sigma of simulate_car_racing (src/examples/car_example.jl:38-40,224-236): after
+ * every real-env step of mpopis_run_trials, single-car slots get x += σx z0, y += σy z1, ψ += δψ (δψ = σψ z2) and (Vx, Vy)
+ * rotated passively by δψ.  z from the slot's Philox stream (mpc_step, 0x40000000).  Default 0 (no draws).  Multi-car and
+ * non-car envs: ignored, like the reference (`sim_type == :cr` only). */
+int  mpopis_set_state_noise(mpopis_handle *h, double sigma_x, double sigma_y, double sigma_psi);
 int  mpopis_run_trials(mpopis_handle *h, int32_t num_steps, int32_t laps, double *records /* B*16 */,
                        double *actions /* NULL or B x (num_steps+1) x as */);
 

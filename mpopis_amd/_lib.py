@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "mpopis_set_env_params", "mpopis_set_track", "mpopis_set_action_bounds", "mpopis_reset",
     "mpopis_set_state", "mpopis_get_state", "mpopis_set_U", "mpopis_get_U", "mpopis_set_Sigma",
     "mpopis_seed", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
-    "mpopis_env_query", "mpopis_get_trajectories", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
+    "mpopis_env_query", "mpopis_get_trajectories", "mpopis_set_state_noise", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
 ]
 
@@ -82,6 +82,7 @@ def lib():
         L.mpopis_env_step.argtypes = [H, _dp, _dp]
         L.mpopis_env_query.argtypes = [H, _dp, _ip, _dp, _dp]
         L.mpopis_get_trajectories.argtypes = [H, _dp]
+        L.mpopis_set_state_noise.argtypes = [H, C.c_double, C.c_double, C.c_double]
         L.mpopis_run_trials.argtypes = [H, C.c_int32, C.c_int32, _dp, _dp]
         L.mpopis_timing_enable.argtypes = [H, C.c_int32]
         L.mpopis_timing_read.argtypes = [H, C.c_char_p, C.c_int32, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]

@@ -431,6 +431,13 @@ int mpopis_policy_step(mpopis_handle* h, const mpopis_noise* noise, double* cont
     return rc;
 }
 
+int mpopis_set_state_noise(mpopis_handle* h, double sigma_x, double sigma_y, double sigma_psi) {
+    if (!h) return MPOPIS_ERR_ARG;
+    if (!(sigma_x >= 0.0 && sigma_y >= 0.0 && sigma_psi >= 0.0)) { h->err = "state noise sigmas must be >= 0"; return MPOPIS_ERR_ARG; }
+    h->noise_sx = sigma_x; h->noise_sy = sigma_y; h->noise_spsi = sigma_psi;
+    return MPOPIS_OK;
+}
+
 int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double* records, double* actions) {
     if (!h || !records) return MPOPIS_ERR_ARG;
     return h->run_trials(num_steps, laps, records, actions);

@@ -38,6 +38,7 @@ struct mpopis_handle {
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
     // Level-3 harness
     double* d_hs = nullptr; int* d_alive = nullptr; const int* alive_gate = nullptr; bool status_sticky = false;
+    double noise_sx = 0.0, noise_sy = 0.0, noise_spsi = 0.0;   // simulate_car_racing state noise (car_example.jl:224-236)
     // bookkeeping
     uint64_t mpc_step = 0;
     std::vector<int> h_status;

@@ -8,6 +8,7 @@
 // cnt > num_steps) is frozen: its `alive` flag gates every kernel of later steps.
 #include "engine.h"
 #include "engine_handle.h"
+#include "philox.h"
 #include <math.h>
 #include <algorithm>
 
@@ -28,11 +29,24 @@ __global__ void k_harness_init(double* hs, int* alive, int B) {
 }
 
 // after env(act): cnt += 1; rew += reward(env); logging; violations; lap counter; termination
-__global__ void k_harness_update(EnvDesc env, const double* x, const int* done_env, const double* reward, const int* iters,
-                                 double* hs, int* alive, const double* control, double* actlog, int step, int num_steps, int laps, int K, int B) {
+struct StateNoise { double sx, sy, spsi; const uint64_t* seeds; };
+__global__ void k_harness_update(EnvDesc env, double* x, const int* done_env, const double* reward, const int* iters,
+                                 double* hs, int* alive, const double* control, double* actlog, int step, int num_steps, int laps, int K, int B,
+                                 StateNoise nz) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B || !alive[b]) return;
     double* h = hs + (size_t)b * kH_N;
+    if (nz.seeds && env.kind == MPOPIS_ENV_CAR && env.ncars == 1) {            // :224-236 (sim_type == :cr only), after reward(env)
+        double z0, z1, z2, z3;
+        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 0, &z0, &z1);
+        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 1, &z2, &z3);
+        double* s = x + (size_t)b * 8;
+        s[0] += nz.sx * z0; s[1] += nz.sy * z1;
+        const double dpsi = nz.spsi * z2;
+        s[2] += dpsi;
+        const double c = cos(dpsi), sn = sin(dpsi), vx = s[3], vy = s[4];      // passive rotation matrix [c s; -s c]
+        s[3] = c * vx + sn * vy; s[4] = -sn * vx + c * vy;
+    }
     if (actlog) for (int i = 0; i < env.as; ++i) actlog[((size_t)b * (num_steps + 1) + step) * env.as + i] = control[(size_t)b * env.as + i];
     h[kH_rollouts] += (double)iters[b] * K;
     const double step_rew = reward[b];
@@ -106,8 +120,10 @@ int mpopis_handle::run_trials(int num_steps, int laps, double* records, double* 
         alive_gate = nullptr;
         if (rc) { status_sticky = false; if (d_actlog) (void)hipFree(d_actlog); return rc; }
         launch_env_step(env, d_x, d_t, d_done, d_control, d_reward, d_status, d_alive, B, stream);
+        const bool noisy = noise_sx != 0.0 || noise_sy != 0.0 || noise_spsi != 0.0;
         hipLaunchKernelGGL(k_harness_update, dim3((B + 63) / 64), dim3(64), 0, stream, env, d_x, d_done, d_reward, d_iters, d_hs, d_alive,
-                           d_control, d_actlog, s, num_steps, laps, K, B);
+                           d_control, d_actlog, s, num_steps, laps, K, B,
+                           StateNoise{noise_sx, noise_sy, noise_spsi, noisy ? d_seeds : (const uint64_t*)nullptr});
         // error status is sticky per call of policy_step_enqueue (it clears d_status): fold it into the host view now and then
         if ((s & 7) == 7 || s == num_steps) {
             (void)hipMemcpyAsync(h_alive.data(), d_alive, sizeof(int) * B, hipMemcpyDeviceToHost, stream);

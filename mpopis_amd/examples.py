@@ -63,9 +63,11 @@ def shard_trials(num_trials, rank, world):
 
 def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="cemppi", laps=2, num_samples=150, horizon=50,
                         λ=10.0, α=1.0, U0=None, cov_mat=None, ais_its=10, λ_ais=20.0, ce_elite_threshold=0.8, ce_Σ_est="ss",
-                        cma_σ=0.75, cma_elite_threshold=0.8, seed=None, log_runs=True, device=0, dist=None, quiet=False):
+                        cma_σ=0.75, cma_elite_threshold=0.8, state_x_sigma=0.0, state_y_sigma=0.0, state_ψ_sigma=0.0,
+                        seed=None, log_runs=True, device=0, dist=None, quiet=False):
     """Returns (records, summary) on rank 0 (None elsewhere).  Differences from the reference harness, all
-    forced by the platform: plotting/GIF options are not offered (out of scope) and state noise σ is 0.
+    forced by the platform: plotting/GIF options are not offered (out of scope); the state noise (single car only,
+    car_example.jl:224-236) is drawn from the trial's device stream instead of the env's MersenneTwister.
     ce_Σ_est defaults to :ss like the reference (car_example.jl:66); :mle is the other supported estimator."""
     pt = str(policy_type).lstrip(":")
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -88,6 +90,7 @@ def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="ce
             eng = Engine("car", num_cars, pt, num_samples, horizon, batch=len(mine), lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
                          elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
                          cma_sigma=cma_σ, seed=seed, device=device, cov=cov_mat, U0=U0)
+            eng.set_state_noise(state_x_sigma, state_y_sigma, state_ψ_sigma)
             r = eng.run_trials(num_steps, laps)
             eng.close()
             rows = [np.concatenate([[k], r[i], [0.0]]) for i, k in enumerate(mine)]
@@ -96,6 +99,7 @@ def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="ce
                 eng = Engine("car", num_cars, pt, num_samples, horizon, batch=1, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
                              elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
                              cma_sigma=cma_σ, seed=seed + k - 1, device=device, cov=cov_mat, U0=U0)
+                eng.set_state_noise(state_x_sigma, state_y_sigma, state_ψ_sigma)
                 r = eng.run_trials(num_steps, laps)
                 eng.close()
                 rows.append(np.concatenate([[k], r[0], [0.0]]))

@@ -1013,6 +1013,13 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
  * ====================================================================================== */
 int orc_run_trial(orc_policy *pol, orc_env *env, uint64_t seed, int num_steps, int laps,
                   orc_trial_record *rec, double *act_log) {
+    return orc_run_trial_noise(pol, env, seed, num_steps, laps, 0.0, 0.0, 0.0, rec, act_log);
+}
+
+/* state_x_sigma / state_y_sigma / state_ψ_sigma: car_example.jl:38-40,224-236 (single car only); the three normals per
+ * step come from the stream (step, 0x40000000) and are only drawn when a sigma is non-zero */
+int orc_run_trial_noise(orc_policy *pol, orc_env *env, uint64_t seed, int num_steps, int laps,
+                        double sx, double sy, double spsi, orc_trial_record *rec, double *act_log) {
     const int K = pol->K, cs = pol->cs, as = pol->as, T = pol->T;
     const int N = (pol->kind == ORC_POL_GMPPI || pol->kind == ORC_POL_MPPI) ? 1 : pol->N;
     size_t nZ = (pol->kind == ORC_POL_MPPI) ? (size_t)K * T * as : (size_t)cs * K;
@@ -1047,6 +1054,17 @@ int orc_run_trial(orc_policy *pol, orc_env *env, uint64_t seed, int num_steps, i
         cnt += 1;
         double step_rew = orc_env_reward(env);                                     /* :210 */
         rew += step_rew;
+        if (is_car && env->ncars == 1 && (sx != 0.0 || sy != 0.0 || spsi != 0.0)) { /* :224-236 */
+            double z[4];
+            orc_philox_normals(seed, (uint32_t)(cnt - 1), 0x40000000u, 4, z);
+            env->state[0] += sx * z[0];
+            env->state[1] += sy * z[1];
+            double dpsi = spsi * z[2];
+            env->state[2] += dpsi;
+            double c = cos(dpsi), sn = sin(dpsi), vx = env->state[3], vy = env->state[4];
+            env->state[3] = c * vx + sn * vy;                                      /* passive rotation [c s; -s c] */
+            env->state[4] = -sn * vx + c * vy;
+        }
         if (!is_car) continue;
         double curr_y = env->state[1];                                             /* :241-253 */
         double vmean = 0, vmax = -INFINITY, bmean = 0, bmax = -INFINITY, d = INFINITY;

@@ -152,6 +152,9 @@ typedef struct {
 int  orc_run_trial(orc_policy *pol, orc_env *env, uint64_t seed, int num_steps, int laps,
                    orc_trial_record *rec, double *act_log /* NULL or (num_steps+1)*as */);
 
+int  orc_run_trial_noise(orc_policy *pol, orc_env *env, uint64_t seed, int num_steps, int laps,
+                         double sx, double sy, double spsi, orc_trial_record *rec, double *act_log);
+
 void orc_quantile_ci(const double *x, int n, double *lo, double *med, double *hi);
 
 #ifdef __cplusplus

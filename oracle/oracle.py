@@ -98,6 +98,8 @@ def lib():
                                         C.c_int, C.c_double, C.c_double, C.c_int, C.c_double]
         L.orc_run_trial.argtypes = [C.POINTER(Policy), C.POINTER(Env), C.c_uint64, C.c_int, C.c_int,
                                     C.POINTER(TrialRecord), _dp]
+        L.orc_run_trial_noise.argtypes = [C.POINTER(Policy), C.POINTER(Env), C.c_uint64, C.c_int, C.c_int,
+                                          C.c_double, C.c_double, C.c_double, C.POINTER(TrialRecord), _dp]
         _lib = L
     return _lib
 
@@ -287,11 +289,12 @@ class OraclePolicy:
             r["res_idx0"] = ridx.reshape(nN, K)
         return r
 
-    def run_trial(self, env, seed, num_steps=200, laps=2, log_actions=False):
+    def run_trial(self, env, seed, num_steps=200, laps=2, log_actions=False, state_noise=(0.0, 0.0, 0.0)):
         rec = TrialRecord()
         acts = np.zeros((num_steps + 1, self.as_)) if log_actions else None
-        st = lib().orc_run_trial(C.byref(self.p), C.byref(env.e), seed, num_steps, laps, C.byref(rec),
-                                 _d(acts) if log_actions else None)
+        st = lib().orc_run_trial_noise(C.byref(self.p), C.byref(env.e), seed, num_steps, laps,
+                                       float(state_noise[0]), float(state_noise[1]), float(state_noise[2]), C.byref(rec),
+                                       _d(acts) if log_actions else None)
         d = {f: getattr(rec, f) for f, _ in TrialRecord._fields_ if f != "lap_t"}
         d["lap_t"] = list(rec.lap_t)
         d["status"] = st

@@ -273,6 +273,29 @@ def test_level3_run_trials_mountaincar(eng_mod, oracle):
     eng.close()
 
 
+def test_level3_run_trials_state_noise(eng_mod, oracle, track):
+    """simulate_car_racing's state_x/y/ψ_sigma (car_example.jl:38-40,224-236): position/heading noise after each real-env
+    step, velocity rotated passively; same Philox draws on both sides."""
+    K, T, N = 128, 15, 3
+    sig = (0.3, 0.2, 0.02)
+    eng = eng_mod.Engine("car", 1, "cemppi", K, T, batch=2, lam=10.0, ais_its=N, elite_threshold=0.8, cov=[0.0625, 0.1], track=track, seed=77)
+    eng.set_state_noise(*sig)
+    rec, acts = eng.run_trials(num_steps=12, laps=2, log_actions=True)
+    xs, _, _ = eng.get_state()
+    quiet = eng_mod.Engine("car", 1, "cemppi", K, T, batch=2, lam=10.0, ais_its=N, elite_threshold=0.8, cov=[0.0625, 0.1], track=track, seed=77)
+    rec0 = quiet.run_trials(num_steps=12, laps=2)
+    quiet.close()
+    assert not np.allclose(rec[:, 0], rec0[:, 0])                       # the noise does change the closed loop
+    for b in range(2):
+        env, pol = make_oracle(oracle, track, "cemppi", 1, K, T, N=N)
+        r = pol.run_trial(env, 77 + b + 1, num_steps=12, laps=2, log_actions=True, state_noise=sig)
+        assert r["status"] == 0 and rec[b, 1] == r["steps"]
+        assert abs(rec[b, 0] - r["rew"]) < 1e-7 * abs(r["rew"])
+        assert np.max(np.abs(acts[b] - r["actions"])) < 1e-7
+        assert np.max(np.abs(xs[b] - env.state)) < 1e-6
+    eng.close()
+
+
 def test_level1_cartpole_with_logger(eng_mod, oracle):
     """CartPole: simulate_model + trajectory logger, ss = 4."""
     rng = np.random.default_rng(31)
