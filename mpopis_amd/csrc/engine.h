@@ -59,6 +59,8 @@ struct RolloutArgs {
     double* cost;          // [B][K]
     double* traj;          // nullptr or [B][K][ss][T] (Julia (T x ss) column-major per sample)
     const int* active;     // nullptr or [B]: slots with active==0 are skipped (AIS early break)
+    int* iters;            // nullptr or [B]: iters[b] = iter_n for every slot this launch works on (AIS iterations executed)
+    int iter_n;
 };
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
@@ -107,7 +109,7 @@ void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, i
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
-                      const double* rscale = nullptr, double* mu_out = nullptr);
+                      const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr);
 bool wcov_mfma_can_emit_mean(int cs);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);

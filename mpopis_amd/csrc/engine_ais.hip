@@ -68,10 +68,10 @@ int mpopis_handle::ais_update(int n, bool injected) {
         if (pol == MPOPIS_POL_MUSIGMAAISMPPI) {
             time_begin(4);
             launch_wcov_mfma(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, 0.0, 10e-9, d_active, stream, nullptr,
-                             one_pass ? d_mu : nullptr);
+                             one_pass ? d_mu : nullptr, one_pass ? d_Ucur : nullptr);     // one pass: also pol.U += μ′
             time_end();
         }
-        hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);   // pol.U += μ′
+        if (!one_pass) hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);   // pol.U += μ′
         return MPOPIS_OK;
     }
     if (pol == MPOPIS_POL_PMCMPPI) {                                                          // :802-809

@@ -35,7 +35,6 @@ __global__ void k_bcast_f64(const double* s, double* d, size_t n, int B) {     /
     size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i < n) for (int b = 0; b < B; ++b) d[(size_t)b * n + i] = s[i];
 }
-__global__ void k_set_iters(int* iters, int n, const int* active, int B) { int b = blockIdx.x * 256 + threadIdx.x; if (b < B && (!active || active[b])) iters[b] = n; }
 
 static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
 static void copy_f64(const double* s_, double* d, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_copy_f64, dim3((n + 255) / 256), dim3(256), 0, s, s_, d, n); }
@@ -506,11 +505,11 @@ void mpopis_handle::prepare_state() {
     if (env.kind == MPOPIS_ENV_CAR) launch_extend_state(d_x, d_xext, B, env.ncars, stream);
 }
 
-void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act) {
+void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters, int iter_n) {
     RolloutArgs a;
     a.env = env; a.B = B; a.K = K; a.T = T; a.cs = cs;
     a.x0 = d_x; a.x0ext = d_xext; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
-    a.cost = d_cost; a.traj = d_traj; a.active = act;
+    a.cost = d_cost; a.traj = d_traj; a.active = act; a.iters = iters; a.iter_n = iter_n;
     time_begin(0);
     launch_rollout(a, stream);
     time_end();
@@ -569,8 +568,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
         if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
         time_end();
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
-        rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active);
-        hipLaunchKernelGGL(k_set_iters, dim3((B + 255) / 256), dim3(256), 0, stream, d_iters, n, d_active, B);
+        rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active, d_iters, n);   // also records iters_run = n for the active slots
         // ---- adapt (μ, Σ′) ----------------------------------------------------------------------
         if (n < N) {
             int rc = ais_update(n, injected);

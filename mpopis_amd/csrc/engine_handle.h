@@ -50,7 +50,7 @@ struct mpopis_handle {
     void time_begin(int slot);
     void time_end();
     void prepare_state();
-    void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act);
+    void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters = nullptr, int iter_n = 0);
     int policy_step_enqueue(bool injected);
     int ais_update(int n, bool injected);
     int run_trials(int num_steps, int laps, double* records, double* actions);

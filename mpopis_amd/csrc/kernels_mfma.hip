@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
 __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
                                                           const double* __restrict__ mu_corr, double wtot_unweighted,
-                                                          double* __restrict__ mu_aug) {
+                                                          double* __restrict__ mu_aug, double* __restrict__ u_add) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
@@ -306,7 +306,10 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
             for (int sp = 0; sp < ksplit; ++sp) m += part[(((size_t)b * ksplit + sp) * npairs + qa) * 256 + ea];
             m = m / swtot;
             smu[threadIdx.x] = m;
-            if (ta == taug && threadIdx.x >= 16 && tb * 16 + jl < cs) mu_aug[(size_t)b * cs + tb * 16 + jl] = m;
+            if (ta == taug && threadIdx.x >= 16 && tb * 16 + jl < cs) {
+                mu_aug[(size_t)b * cs + tb * 16 + jl] = m;
+                if (u_add) u_add[(size_t)b * cs + tb * 16 + jl] += m;          // pol.U += μ′ (:734), one writer per entry
+            }
         }
         __syncthreads();
     }
@@ -414,7 +417,7 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
 bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
-                      double* mu_out) {
+                      double* mu_out, double* u_add) {
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
@@ -436,7 +439,7 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
-                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr);
+                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr);
 }
 
 }  // namespace mpopis

@@ -24,6 +24,7 @@ template <int NC, int SPB, bool LOG>
 __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
+    if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = (NC > 1) ? wave % NC : 0;                   // car of this wave
@@ -117,6 +118,7 @@ template <int SS>
 __global__ void __launch_bounds__(64) k_rollout_simple(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
+    if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int K = a.K, T = a.T;
     const bool valid = k < K;
