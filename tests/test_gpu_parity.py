@@ -296,6 +296,51 @@ def test_level3_run_trials_state_noise(eng_mod, oracle, track):
     eng.close()
 
 
+_FUZZ = [  # (policy, ncars, K, T, N, B)  -- ragged / tiny / awkward shapes through every kernel
+    ("gmppi", 1, 1, 1, 1, 1), ("gmppi", 4, 5, 3, 1, 2), ("mppi", 1, 3, 2, 1, 3), ("mppi", 2, 65, 7, 1, 1),
+    ("imppi", 3, 17, 5, 3, 2), ("muaismppi", 1, 63, 1, 4, 1), ("musigmaaismppi", 1, 33, 4, 3, 2), ("musigmaaismppi", 2, 129, 9, 2, 1),
+    ("musigmaaismppi", 4, 70, 6, 3, 1), ("cemppi", 1, 10, 3, 3, 2), ("cemppi", 2, 47, 5, 4, 1), ("pmcmppi", 1, 31, 3, 3, 2),
+    ("pmcmppi", 3, 90, 4, 2, 1), ("cmamppi", 1, 40, 3, 3, 1), ("cmamppi", 2, 96, 4, 2, 2),
+]
+
+
+@pytest.mark.parametrize("kind,ncars,K,T,N,B", _FUZZ)
+def test_level2_awkward_shapes(eng_mod, oracle, track, kind, ncars, K, T, N, B):
+    """Shapes no BASELINE config uses: K = 1 / below a wave / not a multiple of 64, T = 1, 4 cars, tiny elites, several slots."""
+    from mpopis_amd._lib import MPOPISError
+    rng = np.random.default_rng(K * 131 + T * 17 + ncars)
+    cs = 2 * ncars * T
+    Neff = 1 if kind in ("gmppi", "mppi") else N
+    eng = eng_mod.Engine("car", ncars, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8,
+                         cma_sigma=0.75, cov=np.tile([0.0625, 0.1], ncars), track=track)
+    envs, pols = zip(*[make_oracle(oracle, track, kind, ncars, K, T, N=N) for _ in range(B)])
+    for b in range(B):                                           # different start states per slot
+        st = envs[b].state; st[3] = 10.0 + 2.0 * b; st[1] = 1.5 * b; envs[b].state = st
+    eng.set_state(np.stack([e.state for e in envs]))
+    for step in range(2):
+        if kind == "mppi":
+            Z = rng.standard_normal((B, T, K, 2 * ncars))
+        else:
+            Z = rng.standard_normal((B, Neff, K, cs))
+        di = rng.integers(0, K, (B, max(Neff - 1, 1), K)).astype(np.int32)
+        du = rng.random((B, max(Neff - 1, 1), K))
+        refs = [pols[b](envs[b], Z[b], di[b], du[b]) for b in range(B)]
+        worst = min(r["status"] for r in refs)
+        if worst:                                                 # e.g. rank-deficient elite covariance: same error code
+            with pytest.raises(MPOPISError) as ei:
+                eng.policy_step(Z, di, du)
+            assert ei.value.code == worst
+            break
+        got = eng.policy_step(Z, di, du)
+        U_dev = eng.get_U()
+        for b in range(B):
+            assert got["iters_run"][b] == refs[b]["iters_run"], (kind, b)
+            assert rel_err(got["cost"][b], refs[b]["cost"]) < 1e-7, (kind, step, b)
+            assert np.max(np.abs(got["control"][b] - refs[b]["control"])) < 1e-7
+            assert np.max(np.abs(U_dev[b] - pols[b].U)) < 1e-7
+    eng.close()
+
+
 def test_level1_cartpole_with_logger(eng_mod, oracle):
     """CartPole: simulate_model + trajectory logger, ss = 4."""
     rng = np.random.default_rng(31)
