@@ -265,7 +265,8 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     double sdd, cdd;
-    sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157
+    sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
+    if (fabs(dd) > 0.0625) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 358 deg/s: library path)
     auto substep = [&]() {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators

@@ -341,6 +341,35 @@ def test_level2_awkward_shapes(eng_mod, oracle, track, kind, ncars, K, T, N, B):
     eng.close()
 
 
+@pytest.mark.parametrize("variant", ["heavy_fast_steer", "coarse_dt", "odd_substeps"])
+def test_level1_custom_car_params(eng_mod, oracle, track, variant):
+    """mpopis_set_env_params with non-default CarRacingEnvParams / dt / δt (car_racing.jl:2-21,33-34): other masses, tyres,
+    a steering rate beyond the small-angle range of the per-sub-step rotation (library sin/cos path), other sub-step counts."""
+    rng = np.random.default_rng(5)
+    K, T = 192, 20
+    p = oracle.car_default_params()
+    if variant == "heavy_fast_steer":
+        p[0] = 2600.0; p[1] = 4800.0; p[7] = 1.2e5; p[8] = 2.2e5; p[9] = 0.8; p[10] = 1.0
+        p[12] = np.deg2rad(400.0); p[11] = np.deg2rad(25.0); p[15] = 0.5; p[16] = 0.2      # δ_dot_max, δ_max, λ_brake, λ_drive
+    elif variant == "coarse_dt":
+        p[18] = 0.1; p[19] = 0.02                                # 5 sub-steps
+    else:
+        p[18] = 0.07; p[19] = 0.01                               # 7 sub-steps (odd: remainder of the 2-per-trip loop)
+    env = oracle.OracleEnv("car", 1, params=p, track=track)
+    pol = oracle.OraclePolicy("gmppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1])
+    eng = eng_mod.Engine("car", 1, "gmppi", K, T, batch=1, lam=10.0, cov=[0.0625, 0.1], track=track, env_params=p)
+    E = rng.standard_normal((1, K, 2 * T)) * np.tile([0.6, 0.4], T)
+    got = eng.rollout_costs(np.zeros((1, 2 * T)), E, x0=env.state[None])
+    ref = pol.simulate_model(np.zeros(2 * T), E[0].T)
+    assert rel_err(got[0], ref) < RTOL
+    a = np.array([[0.9, -0.3]])
+    for _ in range(5):                                           # real env step with the same parameters
+        env.step(a[0]); r = eng.env_step(a)
+        x, _, _ = eng.get_state()
+        assert np.max(np.abs(x[0] - env.state)) < 1e-10 and abs(r[0] - env.reward()) < 1e-9 * abs(env.reward())
+    eng.close()
+
+
 def test_level1_cartpole_with_logger(eng_mod, oracle):
     """CartPole: simulate_model + trajectory logger, ss = 4."""
     rng = np.random.default_rng(31)
