@@ -167,7 +167,8 @@ int  mpopis_run_trials(mpopis_handle *h, int32_t num_steps, int32_t laps, double
                        double *actions /* NULL or B x (num_steps+1) x as */);
 
 /* ---- measurement hooks (bench.py; HIP events on the engine's own stream) ----------------------- */
-int  mpopis_timing_enable(mpopis_handle *h, int32_t on);
+int  mpopis_timing_enable(mpopis_handle *h, int32_t on);   /* 0 off; 1 every kernel class; else a mask: bit (i + 1) = class i of
+                                                              * mpopis_timing_read's name list (2 = "rollout" only: 2 events per launch) */
 /* accumulated since enable/reset: per kernel class average launch duration.
  * names: semicolon separated list; ms_total[i], launches[i] for i < *n (in: capacity). */
 int  mpopis_timing_read(mpopis_handle *h, char *names, int32_t names_cap, double *ms_total,

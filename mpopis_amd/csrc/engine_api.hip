@@ -47,14 +47,16 @@ template <class T> static int dalloc(mpopis_handle* h, T** p, size_t n) {
 }
 
 void mpopis_handle::time_begin(int slot) {
-    if (!timing || ev_used + 2 > (int)events.size()) return;
+    ev_open = timing && (timing_mask & (1 << slot)) && ev_used + 2 <= (int)events.size();
+    if (!ev_open) return;
     (void)hipEventRecord(events[ev_used], stream);
     ev_slot.push_back(slot);
 }
 void mpopis_handle::time_end() {
-    if (!timing || ev_used + 2 > (int)events.size()) return;
+    if (!ev_open) return;
     (void)hipEventRecord(events[ev_used + 1], stream);
     ev_used += 2;
+    ev_open = false;
 }
 
 static int sync_status(mpopis_handle* h) {
@@ -450,6 +452,7 @@ int mpopis_timing_enable(mpopis_handle* h, int32_t on) {
         for (auto& e : h->events) HIPCHK(h, hipEventCreate(&e));
     }
     h->timing = on != 0;
+    h->timing_mask = (on == 1 || on == 0) ? ~0 : (on >> 1);     // 1: every class; otherwise bit (class + 1) selects a class
     return MPOPIS_OK;
 }
 int mpopis_timing_reset(mpopis_handle* h) { if (!h) return MPOPIS_ERR_ARG; h->ev_used = 0; h->ev_slot.clear(); return MPOPIS_OK; }

@@ -44,7 +44,7 @@ struct mpopis_handle {
     std::vector<int> h_status;
     double* h_pin = nullptr;          // pinned staging for the small per-step outputs (control, iters)
     // timing
-    bool timing = false;
+    bool timing = false, ev_open = false; int timing_mask = ~0;
     std::vector<hipEvent_t> events; std::vector<int> ev_slot; int ev_used = 0;
 
     void time_begin(int slot);
