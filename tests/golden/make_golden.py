@@ -4,7 +4,8 @@ hot path, at sizes the oracle finishes in milliseconds.
 These vectors are ORACLE-generated (the reference is Julia and cannot run in the build image, see the header of
 oracle/mpopis_oracle.h: parity unpinned).  They serve two purposes: (1) `-m "not gpu"` tests detect any drift of the oracle
 itself, (2) `-m gpu` tests check the HIP engine against committed numbers without calling the oracle.  When a Julia
-toolchain is available, tools/gen_golden.jl produces the same file layout from the real reference.
+toolchain is available, tools/gen_golden.jl dumps the corresponding vectors of the real reference (tests/golden/julia_*.json)
+against which the oracle can then be pinned.
 
     python tests/golden/make_golden.py        # rewrites golden_v1.npz next to this script
 """
