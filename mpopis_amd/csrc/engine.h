@@ -106,6 +106,8 @@ bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B,
                               const int* active, hipStream_t s);
 void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, int n, double alpha, double beta,
                           unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s);
+void launch_gemm_sym_mfma_pair(const double* A1, const double* A2, const double* Bm, double* D1, double* D2, int B, int n,
+                               const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,

@@ -77,8 +77,8 @@ void launch_inv_sqrt_spd(const double* A, double* C, double* Y0, double* Y1, dou
         // T = 1.5 I - 0.5 Z Y  (+ residual max|I - ZY|)
         launch_gemm_sym_mfma(Zc, Yc, Tm, B, n, -0.5, 1.5, rnew, rprev, tol, active, s);
         // Y' = Y T ; Z' = T Z   (slots freeze once converged)
-        launch_gemm_sym_mfma(Yc, Tm, Yn, B, n, 1.0, 0.0, nullptr, rprev, tol, active, s);
-        launch_gemm_sym_mfma(Tm, Zc, Zn, B, n, 1.0, 0.0, nullptr, rprev, tol, active, s);
+        // (T is a polynomial in Z Y, the iterates are symmetric and commute: T Z = Z T, so both products share the right operand)
+        launch_gemm_sym_mfma_pair(Yc, Zc, Tm, Yn, Zn, B, n, rprev, tol, active, s);
         std::swap(Yc, Yn); std::swap(Zc, Zn);
     }
     hipLaunchKernelGGL(k_ns_finish, dim3(((size_t)n * n + 255) / 256, B), dim3(256), 0, s, Z0, Z1, cnorm, resid, iters, B, tol, C, n, active);

@@ -32,13 +32,17 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 //              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
 //              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
 struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; };
+// optional second (left operand, output) pair sharing the right operand: grid.z = 2 * nbatch, z >= nbatch works on (L2, E2)
+struct PairArgs { const double* L2; double* E2; int nbatch; };
 template <bool TRI, bool RNG>
 __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
                                                       double* __restrict__ E, int n, int K, const int* active,
                                                       double alpha, double beta, unsigned long long* resid,
-                                                      const unsigned long long* resid_prev, double tol, RngArgs rng) {
+                                                      const unsigned long long* resid_prev, double tol, RngArgs rng, PairArgs pair) {
     __shared__ double Ls[2][16][kTrmmLd];
-    const int b = blockIdx.z;
+    const bool second = pair.nbatch > 0 && (int)blockIdx.z >= pair.nbatch;
+    const int b = second ? blockIdx.z - pair.nbatch : blockIdx.z;
+    if (second) { L = pair.L2; E = pair.E2; }
     if (active && !active[b]) return;
     if (!TRI && resid_prev && __longlong_as_double((long long)resid_prev[b]) < tol) {
         if (resid && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) resid[b] = resid_prev[b];
@@ -101,7 +105,9 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
         for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * q + lk < n) ? bz[q] : 0.0;
         __syncthreads();
         if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
-        const int tfirst = TRI ? max(0, j0 / 16 - t0) : 0;      // row tiles above the chunk's block row are all zero
+        // TRI: row tiles above the chunk's block row are all zero.  !TRI: the product of the (commuting) symmetric operands is
+        // symmetric, so a wave only computes the tiles on or below the diagonal of its 16 columns and mirrors them on store
+        const int tfirst = TRI ? max(0, j0 / 16 - t0) : max(0, (k0 >> 4) - t0);
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
             if (t >= tfirst && t < nt) {                        // wave-uniform
@@ -121,10 +127,12 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
                     const int i = (t0 + t) * 16 + lk + 4 * r;
                     if (i < n) {
                         if (TRI) Eb[(size_t)i * K + k0 + li] = acc[t][r];
-                        else {
+                        else if (t0 + t >= (k0 >> 4)) {
                             const double ab = acc[t][r], id = (i == k0 + li) ? 1.0 : 0.0;
                             rmax = fmax(rmax, fabs(id - ab));
-                            Eb[(size_t)i * K + k0 + li] = alpha * ab + id * beta;
+                            const double v = alpha * ab + id * beta;
+                            Eb[(size_t)i * K + k0 + li] = v;
+                            if (t0 + t > (k0 >> 4)) Eb[(size_t)(k0 + li) * K + i] = v;         // mirror of a strictly-lower tile
                         }
                     }
                 }
@@ -141,7 +149,7 @@ __global__ void __launch_bounds__(256) k_trmm_LZ_mfma(const double* __restrict__
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true, false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{nullptr, 0, 0});
+                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{nullptr, 0, 0}, PairArgs{nullptr, nullptr, 0});
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
@@ -149,7 +157,7 @@ bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B,
     const int nt = (n + 15) / 16;
     if ((n & 1) || nt > kTrmmTiles) return false;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true, true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{seeds, slo, shi});
+                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{seeds, slo, shi}, PairArgs{nullptr, nullptr, 0});
     return true;
 }
 // D = alpha*(A*Bm) + beta*I for symmetric n x n operands (batched, stride n*n), see k_trmm_LZ_mfma<false>
@@ -157,7 +165,15 @@ void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, i
                           unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<false, false>), dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, A, (size_t)n * n, Bm, D, n, n, active,
-                       alpha, beta, resid, resid_prev, tol, RngArgs{nullptr, 0, 0});
+                       alpha, beta, resid, resid_prev, tol, RngArgs{nullptr, 0, 0}, PairArgs{nullptr, nullptr, 0});
+}
+
+// D1 = A1*Bm and D2 = A2*Bm in ONE launch (same right operand; Newton-Schulz: Y' = Y T, Z' = Z T)
+void launch_gemm_sym_mfma_pair(const double* A1, const double* A2, const double* Bm, double* D1, double* D2, int B, int n,
+                               const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
+    const int nt = (n + 15) / 16;
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<false, false>), dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, 2 * B), dim3(256), 0, s, A1, (size_t)n * n, Bm, D1, n, n, active,
+                       1.0, 0.0, (unsigned long long*)nullptr, resid_prev, tol, RngArgs{nullptr, 0, 0}, PairArgs{A2, D2, B});
 }
 
 // ---------------------------------------------------------------------------------------------
