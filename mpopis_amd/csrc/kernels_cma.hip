@@ -95,20 +95,24 @@ __global__ void __launch_bounds__(256) k_cma_begin(double* scal, double* vec, do
 }
 
 // δw given (gather_mean with cw); this kernel: pol.U += σ δw; pσ; σ; hσ; pΣ; temp_sum
-__global__ void __launch_bounds__(256) k_cma_paths(const double* __restrict__ C, const double* __restrict__ E, const int32_t* __restrict__ order,
+constexpr int kCmaThreads = 1024, kCmaWaves = kCmaThreads / 64;
+__global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restrict__ C, const double* __restrict__ E, const int32_t* __restrict__ order,
                                                    const double* __restrict__ ws, double* Ucur, double* scal, double* vec, double* sig2,
                                                    int cs, int K, int n_iter, CmaConsts cc, const int* active) {
+    extern __shared__ __attribute__((aligned(16))) double part_v[];          // [kCmaWaves][cs] partial C*δw
     const int b = blockIdx.x;
     if (active && !active[b]) return;
-    __shared__ double sh[4];
-    __shared__ double bc[2];
+    __shared__ double sh[kCmaWaves];
     auto block_sum = [&](double v) -> double {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         __syncthreads();
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
         __syncthreads();
-        return sh[0] + sh[1] + sh[2] + sh[3];
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kCmaWaves; ++w) t += sh[w];
+        return t;
     };
     const size_t nn = (size_t)cs * cs;
     const double* Cb = C + (size_t)b * nn;
@@ -117,10 +121,25 @@ __global__ void __launch_bounds__(256) k_cma_paths(const double* __restrict__ C,
     const double sigma_old = scal[b * 8 + 0];
     const double sc = sqrt(cc.c_sigma * (2 - cc.c_sigma) * cc.mu_eff);
     double nps2 = 0.0, fro = 0.0;
-    for (int i = threadIdx.x; i < cs; i += 256) {
+    // C*δw and ||C||_F²: lanes run along rows i (coalesced column reads), the 16 waves split the columns j
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int jper = (cs + kCmaWaves - 1) / kCmaWaves, j0 = wv * jper, j1 = min(cs, j0 + jper);
+        for (int rc = 0; rc < cs; rc += 64) {
+            const int i = rc + lane;
+            double v = 0.0;
+            if (i < cs) {
+                for (int j = j0; j < j1; ++j) { const double cij = Cb[i + (size_t)j * cs]; v = fma(sc * cij, dw[j], v); fro = fma(cij, cij, fro); }
+                part_v[(size_t)wv * cs + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cs; i += kCmaThreads) {
         Ub[i] += sigma_old * dw[i];                                                        // :577
         double v = 0.0;
-        for (int j = 0; j < cs; ++j) { const double cij = Cb[i + (size_t)j * cs]; v = fma(sc * cij, dw[j], v); fro = fma(cij, cij, fro); }
+#pragma unroll
+        for (int w = 0; w < kCmaWaves; ++w) v += part_v[(size_t)w * cs + i];
         const double pn = (1 - cc.c_sigma) * ps[i] + v;                                    // :581
         ps[i] = pn; nps2 = fma(pn, pn, nps2);
     }
@@ -130,12 +149,12 @@ __global__ void __launch_bounds__(256) k_cma_paths(const double* __restrict__ C,
     const double sigma_new = sigma_old * exp(cc.c_sigma / cc.d_sigma * (nps / cc.E_cma - 1));   // :582
     const int h_sigma = (nps / sqrt(1 - pow(1 - cc.c_sigma, 2.0 * n_iter)) < (1.4 + 2.0 / (cs + 1)) * cc.E_cma) ? 1 : 0;   // :585
     const double sS = h_sigma * sqrt(cc.c_Sigma * (2 - cc.c_Sigma) * cc.mu_eff);
-    for (int i = threadIdx.x; i < cs; i += 256) pS[i] = (1 - cc.c_Sigma) * pS[i] + sS * dw[i];   // :586
+    for (int i = threadIdx.x; i < cs; i += kCmaThreads) pS[i] = (1 - cc.c_Sigma) * pS[i] + sS * dw[i];   // :586
     // temp_sum (:588-596): δs[order[ii]] is LINEAR indexing into δs = elite_E/σ (cs x m_elite), a scalar
     const double* Eb = E + (size_t)b * cs * K;
     const int32_t* ob = order + (size_t)b * K;
     double ts = 0.0;
-    for (int ii = threadIdx.x; ii < K; ii += 256) {
+    for (int ii = threadIdx.x; ii < K; ii += kCmaThreads) {
         const int j = ob[ii];                                    // 0-based linear index, requires j < cs*m_elite
         const double d = Eb[(size_t)(j % cs) * K + ob[j / cs]] / sigma_old;
         const double wi = ws[ii];
@@ -149,7 +168,6 @@ __global__ void __launch_bounds__(256) k_cma_paths(const double* __restrict__ C,
         scal[b * 8 + 0] = sigma_new; scal[b * 8 + 1] = ts; scal[b * 8 + 2] = (double)h_sigma; scal[b * 8 + 3] = nps; scal[b * 8 + 4] = fro;
         sig2[b] = sigma_new * sigma_new;
     }
-    (void)bc;
 }
 
 // Σ = (1-c1-cμ)Σ + c1 (pΣ pΣ' + (1-hσ) cΣ (2-cΣ) Σ) .+ cμ temp_sum ; Σ = triu(Σ) + triu(Σ,1)'   (:598-599)
@@ -176,7 +194,7 @@ void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, in
 void launch_cma_paths(const double* C, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
                       double* sig2, int B, int cs, int K, int n_iter, const double* consts7, int m_elite, const int* active, hipStream_t s) {
     CmaConsts cc{consts7[0], consts7[1], consts7[2], consts7[3], consts7[4], consts7[5], consts7[6], m_elite};
-    hipLaunchKernelGGL(k_cma_paths, dim3(B), dim3(256), 0, s, C, E, order, ws, Ucur, scal, vec, sig2, cs, K, n_iter, cc, active);
+    hipLaunchKernelGGL(k_cma_paths, dim3(B), dim3(kCmaThreads), (size_t)kCmaWaves * cs * sizeof(double), s, C, E, order, ws, Ucur, scal, vec, sig2, cs, K, n_iter, cc, active);
 }
 void launch_cma_sigma_update(double* Sig, const double* scal, const double* vec, int B, int cs, const double* consts7, int m_elite,
                              const int* active, hipStream_t s) {
