@@ -46,6 +46,11 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
     // working matrix W (ld = ldw): the LDS copy is padded to a multiple of 16 with an identity tail
     double* W; int ldw, m;
     if (LDS) { W = smem; ldw = npad; m = npad; } else { W = Lb; ldw = n; m = n; }
+    // global-memory variant: the solved panel strip P[m][17] (both operands of the trailing update) and the current diagonal
+    // block D11[16][17] (read by every row of the panel solve) live in LDS; only the trailing read-modify-write goes to L2
+    constexpr int kPS = kNB + 1;
+    double* P = LDS ? nullptr : smem;
+    double* D11 = LDS ? nullptr : smem + (size_t)n * kPS;
     if (tid == 0) failed = 0;
     // copy in the lower triangle only (the upper triangle of W is never consumed): columns c and m-1-c together hold m+1
     // entries, so the triangle is the (m/2) x (m+1) rectangle e -> (c, t); batches of 8 unconditional (clamped) loads in
@@ -116,7 +121,10 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
         }
         if (rowok) {
 #pragma unroll
-            for (int c = 0; c < kNB; ++c) if (c < nb && c <= lane) W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] = d[c];
+            for (int c = 0; c < kNB; ++c) if (c < nb && c <= lane) {
+                W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] = d[c];
+                if (!LDS) D11[lane * kPS + c] = d[c];
+            }
         }
         if (bad && lane == 0) failed = 1;
     };
@@ -129,8 +137,8 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int ra = r0 + li, rb = c0 + li, col = j0 + kk * 4 + lk;
-            const double av = (ra < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0;
-            const double bv = (rb < m) ? W[(size_t)rb + (size_t)col * ldw] : 0.0;
+            const double av = (ra < m) ? (LDS ? W[(size_t)ra + (size_t)col * ldw] : P[(size_t)ra * kPS + kk * 4 + lk]) : 0.0;
+            const double bv = (rb < m) ? (LDS ? W[(size_t)rb + (size_t)col * ldw] : P[(size_t)rb * kPS + kk * 4 + lk]) : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
         }
 #pragma unroll
@@ -155,12 +163,15 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
                 if (c < nb) {
                     double v = x[c];
 #pragma unroll
-                    for (int k = 0; k < c; ++k) v = fma(-x[k], W[(size_t)(j0 + c) + (size_t)(j0 + k) * ldw], v);
+                    for (int k = 0; k < c; ++k) v = fma(-x[k], LDS ? W[(size_t)(j0 + c) + (size_t)(j0 + k) * ldw] : D11[c * kPS + k], v);
                     x[c] = v * rdiag[c];
                 }
             }
 #pragma unroll
-            for (int c = 0; c < kNB; ++c) if (c < nb) W[(size_t)i + (size_t)(j0 + c) * ldw] = x[c];
+            for (int c = 0; c < kNB; ++c) if (c < nb) {
+                W[(size_t)i + (size_t)(j0 + c) * ldw] = x[c];
+                if (!LDS) P[(size_t)i * kPS + c] = x[c];
+            }
         }
         __syncthreads();
         // (3) trailing update with one panel of look-ahead: wave 0 updates the next diagonal tile first and factors it
@@ -198,7 +209,10 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
         hipLaunchKernelGGL((k_potrf<true, 512>), dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
-        hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), 0, s, A, Astride, L, n, n, scale, status, active);
+        const size_t strip = ((size_t)n * (kNB + 1) + kNB * (kNB + 1)) * sizeof(double);     // panel strip + diagonal block
+        static bool attr2 = false;
+        if (!attr2) { (void)hipFuncSetAttribute((const void*)k_potrf<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr2 = true; }
+        hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), strip, s, A, Astride, L, n, n, scale, status, active);
     }
 }
 
