@@ -32,7 +32,7 @@ def make_oracle(oracle, track, kind, ncars, K, T, **kw):
     return env, pol
 
 
-@pytest.mark.parametrize("ncars,K,T", [(1, 256, 50), (1, 150, 50), (3, 128, 50), (2, 70, 13)])
+@pytest.mark.parametrize("ncars,K,T", [(1, 256, 50), (1, 150, 50), (3, 128, 50), (2, 70, 13), (1, 1100, 12), (2, 1030, 8)])
 def test_level1_rollout_costs_car(eng_mod, oracle, track, ncars, K, T):
     rng = np.random.default_rng(100 + ncars)
     B = 2
