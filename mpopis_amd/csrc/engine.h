@@ -68,7 +68,7 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,
-                    int* status, hipStream_t s);
+                    int* status, hipStream_t s, double* wsum = nullptr);
 
 // out[b][r] = Σ_k w[b][k] * (E[b][r][k] + shift[b][r]) / (norm ? Σ_k w : 1)
 void launch_wmean(const double* E, const double* w, const double* shiftA, const double* shiftB,
@@ -111,7 +111,7 @@ void launch_gemm_sym_mfma_pair(const double* A1, const double* A2, const double*
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
-                      const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr);
+                      const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr, const double* wsum = nullptr);
 bool wcov_mfma_can_emit_mean(int cs);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);

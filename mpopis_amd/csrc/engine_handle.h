@@ -19,6 +19,7 @@ struct mpopis_handle {
     bool sigma_diag = false;
     // samples / costs / weights
     double *d_Z = nullptr, *d_E = nullptr, *d_Zin = nullptr, *d_cost = nullptr, *d_w = nullptr;
+    double* d_wsum = nullptr;          // [B] Σ_k w_k of the last k_weights launch of the AIS loop
     double *d_wn = nullptr, *d_mu = nullptr, *d_gvec = nullptr, *d_control = nullptr, *d_reward = nullptr, *d_traj = nullptr;
     int *d_status = nullptr, *d_active = nullptr, *d_iters = nullptr;
     uint64_t* d_seeds = nullptr;

@@ -289,13 +289,14 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
 __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
                                                           const double* __restrict__ mu_corr, double wtot_unweighted,
-                                                          double* __restrict__ mu_aug, double* __restrict__ u_add) {
+                                                          double* __restrict__ mu_aug, double* __restrict__ u_add, const double* __restrict__ wsum) {
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
     __shared__ double sden, swtot;
     __shared__ double smu[32];
-    if (w) {                                                    // Σ_k w_k (ProbabilityWeights)
+    if (w && wsum) { if (threadIdx.x == 0) { swtot = wsum[b]; sden = (den == 0.0) ? swtot : den; } __syncthreads(); }   // precomputed by k_weights
+    else if (w) {                                               // Σ_k w_k (ProbabilityWeights)
         double sacc = 0.0;
         for (int k = threadIdx.x; k < K; k += 256) sacc += w[(size_t)b * K + k];
 #pragma unroll
@@ -433,7 +434,7 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
 bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
-                      double* mu_out, double* u_add) {
+                      double* mu_out, double* u_add, const double* wsum) {
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
@@ -455,7 +456,7 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
-                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr);
+                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr, wsum);
 }
 
 }  // namespace mpopis

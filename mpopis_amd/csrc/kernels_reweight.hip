@@ -34,7 +34,7 @@ __device__ __forceinline__ double block_reduce(double v, double* sh) {
 }
 
 __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cost, double* __restrict__ w, int K,
-                                                  double neg_inv_lambda, const int* active, int* status) {
+                                                  double neg_inv_lambda, const int* active, int* status, double* __restrict__ wsum) {
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[16];
@@ -50,12 +50,17 @@ __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cos
         wo[k] = e; s += e;
     }
     s = block_reduce<false>(s, sh);                                            // η
-    for (int k = threadIdx.x; k < K; k += blockDim.x) wo[k] = wo[k] / s;
+    double t = 0.0;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) { const double v = wo[k] / s; wo[k] = v; t += v; }
+    if (wsum) {                                                                // Σ_k w_k of the normalised weights (≈ 1), for the scatter finish
+        t = block_reduce<false>(t, sh);
+        if (threadIdx.x == 0) wsum[b] = t;
+    }
     if (bad && status) atomicMin(&status[b], MPOPIS_ERR_ACTION);               // non-finite cost <=> NaN action (car_racing.jl:239)
 }
 
-void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active, int* status, hipStream_t s) {
-    hipLaunchKernelGGL(k_weights, dim3(B), dim3(K >= 1024 ? 1024 : 256), 0, s, cost, w, K, -1 / lambda, active, status);
+void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active, int* status, hipStream_t s, double* wsum) {
+    hipLaunchKernelGGL(k_weights, dim3(B), dim3(K >= 1024 ? 1024 : 256), 0, s, cost, w, K, -1 / lambda, active, status, wsum);
 }
 
 __global__ void __launch_bounds__(256) k_wmean(const double* __restrict__ E, const double* __restrict__ w,
