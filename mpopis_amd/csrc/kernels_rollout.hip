@@ -67,10 +67,13 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
     __shared__ double sh_cost[SPB][NC][64];
 
     double cost = 0.0, cc = 0.0;
-    double e0 = Eb[0], e1 = Eb[K];
+    double e0 = Eb[0], e1 = Eb[K], u0 = Ub[0], u1 = Ub[1];
     for (int t = 0; t < T; ++t) {
-        const double v0 = Ub[t * as] + e0, v1 = Ub[t * as + 1] + e1;           // V = pol.U + E[:,k]  :271
-        if (t + 1 < T) { e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K]; }
+        const double v0 = u0 + e0, v1 = u1 + e1;                               // V = pol.U + E[:,k]  :271
+        if (t + 1 < T) {                                                       // next step's noise (global) and nominal control (scalar) in flight during this step
+            e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
+            u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
+        }
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
         const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
         car_action_step<LOG>(p, s, a0, a1);
