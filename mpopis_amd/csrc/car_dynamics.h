@@ -169,19 +169,18 @@ MP_HD void car_state_to8(const CarState& c, double* s) {
     s[0] = c.x; s[1] = c.y; s[2] = c.psi; s[3] = c.Vx; s[4] = c.Vy; s[5] = c.r; s[6] = c.delta; s[7] = c.pedal;
 }
 
-// sin/cos for |v| <= 1/16 (truncation < 3e-20 relative): the per-sub-step yaw increment
+// sin/cos for |v| <= kTinyAngle = 1/32: the per-sub-step yaw / steering increments.  Truncation: sin v^9/9! (2.5e-18
+// relative), cos v^8/8! (2.3e-17 absolute) -- below half an ulp, with 4 + 3 VALU ops after v^2.
+constexpr double kTinyAngle = 0.03125;
 MP_HD void sincos_tiny(double v, double* s, double* c) {
     const double v2 = v * v;
-    double ps = 1.0 / 362880.0;
-    ps = fma_v(ps, v2, -1.0 / 5040.0);
+    double ps = -1.0 / 5040.0;
     ps = fma_v(ps, v2, 1.0 / 120.0);
     ps = fma_v(ps, v2, -1.0 / 6.0);
     *s = fma(ps * v2, v, v);
-    // 1/40320 and 1/24 are written one ulp high: their exact low dwords coincide with those of -1/5040 and -1/6, and
-    // hipcc then rebuilds the shared halves with a v_mov per use inside the sub-step loop (the ulp is invisible: these
-    // coefficients multiply v^8 and v^4 with |v| <= 1/16)
-    double pc = 0x1.a01a01a01a01bp-16;
-    pc = fma_v(pc, v2, -1.0 / 720.0);
+    // 1/24 is written one ulp high: its exact low dword coincides with that of -1/6, and hipcc then rebuilds the shared
+    // half with a v_mov per use inside the sub-step loop (the ulp is invisible: the coefficient multiplies v^4)
+    double pc = -1.0 / 720.0;
     pc = fma_v(pc, v2, 0x1.5555555555556p-5);
     pc = fma_v(pc, v2, -0.5);
     *c = fma(pc, v2, 1.0);
@@ -225,8 +224,8 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     double dpsi = r * p.ddt;
     if (PSI) psi += dpsi;
     int nrot = 1;
-    if (fabs(dpsi) > 0.0625) {                                 // |psi_dot| > 6.25 rad/s: split the rotation into <= 1/16 rad pieces
-        nrot = (int)fmin(ceil(fabs(dpsi) * 16.0), 4096.0);
+    if (fabs(dpsi) > kTinyAngle) {                             // |psi_dot| > 3.125 rad/s: split the rotation into <= 1/32 rad pieces
+        nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
         dpsi = dpsi / nrot;
         if (PSI) psi = fmod(psi, kTwoPi);
     }
@@ -266,7 +265,7 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
-    if (fabs(dd) > 0.0625) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 358 deg/s: library path)
+    if (fabs(dd) > kTinyAngle) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
     auto substep = [&]() {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
@@ -291,11 +290,11 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         const double dpsi = r * p.ddt;
         if (PSI) psi += dpsi;                                                  // :329
         double sq, cq;
-        sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/16 ...
+        sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/32 ...
         const double sp0 = sp, cp0 = cp;
         { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-        if (fabs(dpsi) > 0.0625) {                             // ... |psi_dot| > 6.25 rad/s: redo in pieces of <= 1/16 rad
-            const int nrot = (int)fmin(ceil(fabs(dpsi) * 16.0), 4096.0);
+        if (fabs(dpsi) > kTinyAngle) {                         // ... |psi_dot| > 3.125 rad/s (a spin): redo in pieces of <= 1/32 rad
+            const int nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
             sincos_tiny(dpsi / nrot, &sq, &cq);
             sp = sp0; cp = cp0;
             for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
