@@ -90,6 +90,17 @@ MP_HD double clampd_u(double v, double lo, double hi) {
 #endif
 }
 
+// one Newton step on the v_rcp_f64 seed: <= 19 ulp (2.1e-15, measured in tools/rcp_acc.hip) -- used only for the slip tangents
+// of the hot sub-step, where the result feeds a cubic whose own evaluation carries a comparable rounding error
+MP_HD double fast_rcp1(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rcp(v);
+    return fma(fma(-v, r, 1.0), r, r);
+#else
+    return 1.0 / v;
+#endif
+}
+
 MP_HD double fast_rcp(double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // v_rcp_f64 seed + 2 Newton steps: <= 1 ulp for normal-range inputs (Vx, rotated Vx here)
@@ -274,7 +285,7 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
             return;
         }
-        const double rinv = fast_rcp(Vx * xq);
+        const double rinv = fast_rcp1(Vx * xq);
         const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
         // the brush model is C1 at the switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259): evaluating
         // the cubic at the clamped tangent is the same function (the cubic at +-thr is -+fy_max up to rounding)
