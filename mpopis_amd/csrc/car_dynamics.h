@@ -256,15 +256,19 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
 // only consume sin/cos(psi), which are carried by rotation, so rollouts that do not log trajectories never need it
 // (c.psi is then left untouched = stale).
 template <bool PSI = true>
-MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1) {
+MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1, bool renorm = true) {
     double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r;
     double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
-    {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation)
+    if (renorm) {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation; the norm drifts by ~1e-16 per rotation,
+                    // so callers inside long rollouts may do this every few steps only)
         const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
         sp *= fp; cp *= fp; sd *= fd; cd *= fd;
     }
     const double tgt = a0 * p.dmax - c.delta;
-    const double rate = fmin(fabs(tgt) * p.inv_dt, p.ddotmax) * jl_sign(tgt);  // :295-296
+    // :295-296  min(|tgt|/dt, δ_dot_max)·sign(tgt): the magnitude is 0 when tgt is ±0, so copysign is the same function;
+    // a NaN target (NaN action) must stay NaN (fmin would drop it)
+    const double rmag = fmin(fabs(tgt) * p.inv_dt, p.ddotmax);
+    const double rate = (tgt != tgt) ? tgt : copysign(rmag, tgt);
     const double dd = rate * p.ddt;
     const double pedal = a1;                                                   // :297
     // forces and brush-model constants for sign(Vx) = +1, constant over the sub-steps (:310-318)

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
         }
         if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
         const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
-        car_action_step<LOG>(p, s, a0, a1);
+        car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
         if (NC > 1) {                                                          // multi-car_racing.jl:145-158
             const int buf = t & 1;
