@@ -124,7 +124,10 @@ def main():
     ms_dev, rollouts = eng.bench_policy_steps(args.steps)
     # summary stats only: per-trial record (control + mean cost) gathered to rank 0 over RCCL
     if dist is not None:
-        rec = torch.zeros(B, 4, device="cuda", dtype=torch.float64)
+        # per-trial summary (first planned control pair of the rolled U + its norm): the only data that ever leaves a GPU
+        Uh = eng.get_U()
+        rec = torch.tensor(np.concatenate([Uh[:, :2], np.linalg.norm(Uh, axis=1, keepdims=True), np.full((B, 1), float(rank))], 1),
+                           device="cuda", dtype=torch.float64)
         gl = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
         dist.gather(rec, gl, dst=0)
     sync()
