@@ -216,8 +216,8 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0) * sg;        // :310-312
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
-    const TireK kf = tire_consts(p.muf, p.Caf, (p.m * p.lr * 9.81 - p.h * fx) / p.L, fxf);
-    const TireK kr = tire_consts(p.mur, p.Car, (p.m * p.lf * 9.81 + p.h * fx) / p.L, fxr);
+    const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);         // :262-272 (same derived constants as the hot path)
+    const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     const double fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;                               // :308
     const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
     double fyr;
