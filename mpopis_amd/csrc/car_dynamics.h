@@ -319,9 +319,10 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                            // :331
         y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                               // :332
     };
-    int it = 0;
-    for (; it + 1 < p.nsub; it += 2) { substep(); substep(); }                 // two per trip: no loop-carried register copies
-    if (it < p.nsub) substep();
+    for (int it = 0; it < p.nsub; it += 2) {                                   // two per trip: no loop-carried register copies
+        substep();
+        if (it + 1 < p.nsub) substep();                                        // (odd sub-step counts: wave-uniform branch)
+    }
     // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
     double delta = c.delta;
     if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
