@@ -280,12 +280,12 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
-    if (fabs(dd) > kTinyAngle) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
+    if (__builtin_expect(fabs(dd) > kTinyAngle, 0)) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
     auto substep = [&]() {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
-        if (!(Vx > 0.0 && xq > 0.0)) {                                         // cold: stopped / sliding backwards / NaN
+        if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
             return;
         }
@@ -308,7 +308,7 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/32 ...
         const double sp0 = sp, cp0 = cp;
         { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-        if (fabs(dpsi) > kTinyAngle) {                         // ... |psi_dot| > 3.125 rad/s (a spin): redo in pieces of <= 1/32 rad
+        if (__builtin_expect(fabs(dpsi) > kTinyAngle, 0)) {    // ... |psi_dot| > 3.125 rad/s (a spin): redo in pieces of <= 1/32 rad
             const int nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
             sincos_tiny(dpsi / nrot, &sq, &cq);
             sp = sp0; cp = cp0;
@@ -343,7 +343,7 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
     int mi = -1;
     double best = 0.0;
     const int a0 = anchor ? *anchor : -1;
-    if (a0 >= 0 && tk.nbr_idx) {
+    if (__builtin_expect(a0 >= 0 && tk.nbr_idx, 1)) {
         const int S = tk.nbrw + 1;
         mi = a0;
         best = fma(tk.y[a0], m2y, fma(tk.x[a0], m2x, tk.n2[a0]));
@@ -355,9 +355,9 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
             const double d = fma(tk.y[j], m2y, fma(tk.x[j], m2x, tk.n2[j]));
             if (d < best || (d == best && j < mi)) { best = d; mi = j; }
         }
-        if (!closed && tk.nbrw < tk.P) mi = -1;                 // list exhausted before the bound: full scan
+        if (__builtin_expect(!closed && tk.nbrw < tk.P, 0)) mi = -1;   // list exhausted before the bound: full scan
     }
-    if (mi < 0) {
+    if (__builtin_expect(mi < 0, 0)) {
         mi = 0;
         best = fma(tk.y[0], m2y, fma(tk.x[0], m2x, tk.n2[0]));
 #pragma unroll 8
