@@ -235,7 +235,7 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     double dpsi = r * p.ddt;
     if (PSI) psi += dpsi;
     int nrot = 1;
-    if (fabs(dpsi) > kTinyAngle) {                             // |psi_dot| > 3.125 rad/s: split the rotation into <= 1/32 rad pieces
+    if (__builtin_expect(fabs(dpsi) > kTinyAngle, 0)) {        // |psi_dot| > 3.125 rad/s: split the rotation into <= 1/32 rad pieces
         nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
         dpsi = dpsi / nrot;
         if (PSI) psi = fmod(psi, kTwoPi);
@@ -259,7 +259,7 @@ template <bool PSI = true>
 MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1, bool renorm = true) {
     double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r;
     double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
-    if (renorm) {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation; the norm drifts by ~1e-16 per rotation,
+    if (__builtin_expect(renorm, 0)) {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation; the norm drifts by ~1e-16 per rotation,
                     // so callers inside long rollouts may do this every few steps only)
         const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
         sp *= fp; cp *= fp; sd *= fd; cd *= fd;

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
             e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
             u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
         }
-        if (gv) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V)
+        if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V; γ = 0 in every reference config)
         const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
         car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
