@@ -70,20 +70,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int gi = t0 * 16 + si, gic = min(gi, n - 1);
     double lreg[8], bz[4];
     const uint64_t seed = RNG ? rng.seeds[b] : 0;
-    auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4q+lk of the stream
-        double z0[2], z1[2];
+    // MFMA slot (q, lk) of a chunk carries column j0 + 4*lk + q of L (and row j0 + 4*lk + q of Z): a lane's four B operands are
+    // then two ADJACENT row pairs of one sample = exactly two Philox / Box-Muller pairs, drawn by the lane that consumes them
+    // (no cross-lane redistribution).  The LDS panel stores column c in row (c & 3) * 4 + (c >> 2), so that the A-operand
+    // reads keep their conflict-free pattern Ls[4q + lk][..].
+    auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4lk+q of the stream
+        const int kk = min(k0 + li, K - 1);
 #pragma unroll
         for (int rho = 0; rho < 2; ++rho) {
-            const int pr = lane + 64 * rho, smp = pr & 15, rp = pr >> 4;              // pair -> (sample, row pair)
-            const int row = j0 + 2 * rp, kk = min(k0 + smp, K - 1);
+            const int row = j0 + 4 * lk + 2 * rho;
             const uint64_t lin = (uint64_t)kk * n + min(row, n - 2);
-            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, &z0[rho], &z1[rho]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int src = li + 16 * (((2 * q) & 3) + (lk >> 1));
-            const double a0 = __shfl(z0[q >> 1], src, 64), a1 = __shfl(z1[q >> 1], src, 64);
-            bz[q] = (lk & 1) ? a1 : a0;
+            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, &bz[2 * rho], &bz[2 * rho + 1]);
         }
     };
     auto load_chunk = [&](int j0) {
@@ -94,17 +91,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (RNG) draw_chunk(j0);
         else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int j = min(j0 + 4 * q + lk, n - 1); bz[q] = Zb[(size_t)j * K + kcol]; }
+            for (int q = 0; q < 4; ++q) { const int j = min(j0 + 4 * lk + q, n - 1); bz[q] = Zb[(size_t)j * K + kcol]; }
         }
     };
     load_chunk(0);
     int buf = 0;
     for (int j0 = 0; j0 < jend; j0 += 16, buf ^= 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int j = j0 + sj + 2 * u; Ls[buf][sj + 2 * u][si] = (gi < n && j < n && (!TRI || j <= gi)) ? lreg[u] : 0.0; }
+        for (int u = 0; u < 8; ++u) {
+            const int jc = sj + 2 * u, j = j0 + jc;
+            Ls[buf][(jc & 3) * 4 + (jc >> 2)][si] = (gi < n && j < n && (!TRI || j <= gi)) ? lreg[u] : 0.0;
+        }
         double bc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * q + lk < n) ? bz[q] : 0.0;
+        for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * lk + q < n) ? bz[q] : 0.0;
         __syncthreads();
         if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
         // TRI: row tiles above the chunk's block row are all zero.  !TRI: the product of the (commuting) symmetric operands is
