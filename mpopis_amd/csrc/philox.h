@@ -26,7 +26,14 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     const double two_m53 = 1.0 / 9007199254740992.0;
     const double u1 = ((double)(a >> 11) + 0.5) * two_m53;
     const double u2 = ((double)(b >> 11) + 0.5) * two_m53;
-    const double R = sqrt(-2.0 * log(u1));
+    // sqrt of a positive normal-range number: v_rsq_f64 seed + coupled Newton step + residual correction (1 ulp, see
+    // tools/rcp_acc.hip) instead of the library sqrt with its denormal rescaling (8 instead of 18 VALU ops)
+    const double v = -2.0 * log(u1);
+    const double y = __builtin_amdgcn_rsq(v);
+    double g = v * y, h = 0.5 * y;
+    const double rr = fma(-h, g, 0.5);
+    g = fma(g, rr, g); h = fma(h, rr, h);
+    const double R = fma(fma(-g, g, v), h, g);
     double s, c;
     sincospi(2.0 * u2, &s, &c);                                 // = sin/cos(2π u2), no Payne-Hanek reduction
     *z0 = R * c; *z1 = R * s;
