@@ -19,6 +19,26 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// log(u) for a normal-range u in (0, 1): the classic argument reduction u = 2^k m, m in [sqrt(1/2), sqrt(2)), s = f/(2+f),
+// f = m - 1, and the degree-14 odd minimax polynomial in s of Sun's fdlibm (e_log.c; error < 1 ulp).  No special cases
+// (the Box-Muller uniforms are (i + 0.5) 2^-53), no double-double arithmetic: ~35 VALU ops.
+__device__ __forceinline__ double log_unit(double u) {
+    int k = __builtin_amdgcn_frexp_exp(u);                     // u = m 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(u);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m; k = lo ? k - 1 : k;                    // m in [sqrt(1/2), sqrt(2))
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double rd = __builtin_amdgcn_rcp(d);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    rd = fma(fma(-d, rd, 1.0), rd, rd);
+    const double s = f * rd, z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
 __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, double* z0, double* z1) {
     uint32_t r[4];
     philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
@@ -28,7 +48,7 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     const double u2 = ((double)(b >> 11) + 0.5) * two_m53;
     // sqrt of a positive normal-range number: v_rsq_f64 seed + coupled Newton step + residual correction (1 ulp, see
     // tools/rcp_acc.hip) instead of the library sqrt with its denormal rescaling (8 instead of 18 VALU ops)
-    const double v = -2.0 * log(u1);
+    const double v = -2.0 * log_unit(u1);
     const double y = __builtin_amdgcn_rsq(v);
     double g = v * y, h = 0.5 * y;
     const double rr = fma(-h, g, 0.5);
