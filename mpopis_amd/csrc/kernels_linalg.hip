@@ -56,22 +56,26 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
     // entries, so the triangle is the (m/2) x (m+1) rectangle e -> (c, t); batches of 8 unconditional (clamped) loads in
     // flight per thread, select afterwards.  (m even: npad is a multiple of 16; the global-memory variant keeps m = n.)
     if (LDS) {
-        const int tot = (m / 2) * (m + 1);
-        for (int e0 = tid; e0 < tot; e0 += NTHR * 8) {
-            double av[8];
+        constexpr int NW = NTHR / 64;
+        // column pair c (columns c and m-1-c) holds m+1 triangle entries t: wave -> pairs, lane -> t (no integer divisions);
+        // 4 pairs x 2 lane chunks = 8 unconditional (clamped) loads in flight per thread, select afterwards
+        const int npairs2 = m / 2, tchunks = (m + 1 + 63) / 64;
+        for (int c0 = wv * 4; c0 < npairs2; c0 += NW * 4) {
+            for (int tc = 0; tc < tchunks; tc += 2) {
+                double av[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + u * NTHR, tot - 1), c = e / (m + 1), t = e - c * (m + 1);
-                const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * NTHR;
-                if (e < tot) {
-                    const int c = e / (m + 1), t = e - c * (m + 1);
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(c0 + (u >> 1), npairs2 - 1), t = min((tc + (u & 1)) * 64 + lane, m);
                     const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                    W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
+                    av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + (u >> 1), t = (tc + (u & 1)) * 64 + lane;
+                    if (c < npairs2 && t <= m && tc + (u & 1) < tchunks) {
+                        const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                        W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
+                    }
                 }
             }
         }
