@@ -39,6 +39,33 @@ __device__ __forceinline__ double log_unit(double u) {
     return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
 }
 
+// (sin, cos)(2 pi u) for u in (0, 1): octant q = floor(8u), f = frac(8u) (both exact), reflected in odd octants, then the
+// fdlibm kernel polynomials on [0, pi/4] (k_sin.c / k_cos.c; < 1 ulp each) and the octant symmetries.  No large-argument
+// path, no special cases: ~35 VALU ops (OCML's sincospi: ~50 + its constants).
+__device__ __forceinline__ void sincos_2pi_unit(double u, double* sn, double* cs) {
+    const double t = 8.0 * u;
+    const double fl = __builtin_floor(t);
+    const int q = (int)fl;
+    double f = t - fl;
+    f = (q & 1) ? 1.0 - f : f;
+    const double y = f * 0.78539816339744830962, z = y * y;
+    double r = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    r = fma(z, r, 2.75573137070700676789e-06);
+    r = fma(z, r, -1.98412698298579493134e-04);
+    r = fma(z, r, 8.33333333332248946124e-03);
+    const double s = fma(z * y, fma(z, r, -1.66666666666666324348e-01), y);
+    double c = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    c = fma(z, c, -2.75573143513906633035e-07);
+    c = fma(z, c, 2.48015872894767294178e-05);
+    c = fma(z, c, -1.38888888888741095749e-03);
+    c = fma(z, c, 4.16666666666666019037e-02);
+    c = fma(z * z, c, fma(-0.5, z, 1.0));
+    const bool swap = ((q + 1) & 2) != 0;                      // octants 1, 2, 5, 6
+    const double ss = swap ? c : s, cc = swap ? s : c;
+    *sn = (q & 4) ? -ss : ss;                                  // lower half plane
+    *cs = ((q + 2) & 4) ? -cc : cc;                            // left half plane (octants 2..5)
+}
+
 __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, double* z0, double* z1) {
     uint32_t r[4];
     philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
@@ -55,7 +82,7 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     g = fma(g, rr, g); h = fma(h, rr, h);
     const double R = fma(fma(-g, g, v), h, g);
     double s, c;
-    sincospi(2.0 * u2, &s, &c);                                 // = sin/cos(2π u2), no Payne-Hanek reduction
+    sincos_2pi_unit(u2, &s, &c);                                // = sin/cos(2π u2)
     *z0 = R * c; *z1 = R * s;
 }
 
