@@ -69,10 +69,10 @@ __device__ __forceinline__ void sincos_2pi_unit(double u, double* sn, double* cs
 __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, double* z0, double* z1) {
     uint32_t r[4];
     philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    const uint64_t a = ((uint64_t)r[1] << 32) | r[0], b = ((uint64_t)r[3] << 32) | r[2];
-    const double two_m53 = 1.0 / 9007199254740992.0;
-    const double u1 = ((double)(a >> 11) + 0.5) * two_m53;
-    const double u2 = ((double)(b >> 11) + 0.5) * two_m53;
+    // u = ((a >> 11) + 0.5) 2^-53 for the 64-bit word a = (hi:lo), one rounding: (a >> 11) = hi 2^21 + (lo >> 11), so
+    // u = hi 2^-32 + ((lo >> 11) + 0.5) 2^-53 with both conversions exact -- two v_cvt_f64_u32 and two fmas per uniform
+    const double u1 = fma((double)r[1], 0x1p-32, fma((double)(r[0] >> 11), 0x1p-53, 0x1p-54));
+    const double u2 = fma((double)r[3], 0x1p-32, fma((double)(r[2] >> 11), 0x1p-53, 0x1p-54));
     // sqrt of a positive normal-range number: v_rsq_f64 seed + coupled Newton step + residual correction (1 ulp, see
     // tools/rcp_acc.hip) instead of the library sqrt with its denormal rescaling (8 instead of 18 VALU ops)
     const double v = -2.0 * log_unit(u1);
