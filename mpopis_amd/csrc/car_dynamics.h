@@ -48,6 +48,7 @@ struct CarParams {
     int blim_acute;      // β_limit < pi/2
     double inv_m, inv_Izz, L, tan_blim, inv_dt, inv_L, fz0f, fz0r;
     double k_v, k_rf, k_rr;   // δt/m, δt l_f/Izz, δt l_r/Izz (Euler updates of :326-328 with the constants folded)
+    double mfz_f0, mfz_f1, mfz_r0, mfz_r1;   // μ f_z(fx) = mfz_0 -/+ mfz_1 fx for the front / rear axle (:262-272 with μ folded in)
 };
 
 MP_HD CarParams make_car_params(const double* p) {
@@ -61,6 +62,7 @@ MP_HD CarParams make_car_params(const double* p) {
     c.inv_dt = 1 / c.dt; c.inv_L = 1 / c.L;
     c.fz0f = c.m * c.lr * 9.81; c.fz0r = c.m * c.lf * 9.81;                    // :262-272
     c.k_v = c.ddt * c.inv_m; c.k_rf = c.ddt * c.inv_Izz * c.lf; c.k_rr = c.ddt * c.inv_Izz * c.lr;
+    c.mfz_f0 = c.muf * c.fz0f * c.inv_L; c.mfz_f1 = c.muf * c.h * c.inv_L; c.mfz_r0 = c.mur * c.fz0r * c.inv_L; c.mfz_r1 = c.mur * c.h * c.inv_L;
     c.blim_acute = c.blim < 0.5 * kPi;
     c.tan_blim = c.blim_acute ? tan(c.blim) : tan(kPi - c.blim);
     return c;
@@ -157,9 +159,9 @@ MP_HD double fma_v(double a, double b, double c) {
 
 struct TireK { double fymax, thr, k2, k3; };
 
-MP_HD TireK tire_consts(double mu, double Ca, double fzt, double fxt) {
+MP_HD TireK tire_consts(double mufz, double Ca, double fxt) {                  // mufz = μ f_z
     TireK k;
-    k.fymax = fast_sqrt(fmax((mu * fzt) * (mu * fzt) - fxt * fxt, 1e-8));      // :253
+    k.fymax = fast_sqrt(fmax(mufz * mufz - fxt * fxt, 1e-8));                  // :253
     const double rf = fast_rcp(k.fymax), rc = 1.0 / Ca;        // rc: Ca is wave-uniform
     k.thr = 3 * k.fymax * rc;                                  // tan of the switch angle :255
     k.k2 = ((Ca * Ca) * (1.0 / 3.0)) * rf;                     // C^2/(3 fy_max)
@@ -216,8 +218,8 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0) * sg;        // :310-312
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
-    const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);         // :262-272 (same derived constants as the hot path)
-    const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
+    const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);                  // :262-272 (same derived constants as the hot path)
+    const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
     const double fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;                               // :308
     const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
     double fyr;
@@ -276,8 +278,8 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
     const double fxr0 = fxr - p.CD0;                           // rear drive force minus the constant part of the drag (:308)
-    const TireK kf = tire_consts(p.muf, p.Caf, (p.fz0f - p.h * fx) * p.inv_L, fxf);
-    const TireK kr = tire_consts(p.mur, p.Car, (p.fz0r + p.h * fx) * p.inv_L, fxr);
+    const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);
+    const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
     if (__builtin_expect(fabs(dd) > kTinyAngle, 0)) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
