@@ -230,10 +230,12 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     double fyf;
     if (xq > 0.0 && fabs(yq / xq) < kf.thr) fyf = tire_poly(yq / xq, p.Caf, kf);
     else fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -kf.fymax : kf.fymax;
-    const double rdd = p.inv_Izz * (p.lf * (fxf * sd + fyf * cd) - p.lr * fyr);
-    const double Vyd = p.inv_m * (fyf * cd + fxf * sd + fyr) - r * Vx;
-    const double Vxd = p.inv_m * (fxf * cd - fyf * sd + fxr - fx_aero) + r * Vy;
-    r += rdd * p.ddt; Vx += Vxd * p.ddt; Vy += Vyd * p.ddt;
+    // :322-328 with the same δt-folded constants as the hot path (k_rf = δt l_f/Izz, k_rr = δt l_r/Izz, k_v = δt/m)
+    const double flat = fma(fyf, cd, fxf * sd), flon = fma(fxf, cd, -(fyf * sd)), rd = r * p.ddt;
+    const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));
+    const double Vx1 = fma(p.k_v, flon + (fxr - fx_aero), fma(rd, Vy, Vx));
+    r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));
+    Vx = Vx1; Vy = Vy1;
     double dpsi = r * p.ddt;
     if (PSI) psi += dpsi;
     int nrot = 1;
