@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (gpurun_out/pmc_r01/*/pmc_counter_collection.csv) per kernel:
-mean counter value per dispatch and mean duration.  Writes profiles/r01k_pmc_summary.csv and
+mean counter value per dispatch and mean duration.  Writes profiles/r01l_pmc_summary.csv and
 profiles/pmc_rollout.json (HBM bytes per launch of the rollout kernel, used by bench.py)."""
 import csv, glob, json, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01"
@@ -21,7 +21,7 @@ for k in sorted(acc, key=lambda k: -sum(dur[k])):
         row[c] = sum(v) / len(v) if v else ""
     rows.append(row)
 os.makedirs("profiles", exist_ok=True)
-with open("profiles/r01k_pmc_summary.csv", "w", newline="") as fo:
+with open("profiles/r01l_pmc_summary.csv", "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=["kernel", "dispatches_per_pass", "avg_us"] + names)
     w.writeheader()
     w.writerows(rows)
