@@ -118,6 +118,15 @@ int  mpopis_set_U(mpopis_handle *h, const double *U /* B*cs */);            /* p
 int  mpopis_get_U(mpopis_handle *h, double *U /* B*cs */);
 int  mpopis_set_Sigma(mpopis_handle *h, const double *Sigma, int32_t n);    /* pol.Σ : n = as (mppi, or block-replicated :76-78) or cs; col-major, shared by all slots */
 int  mpopis_seed(mpopis_handle *h, uint64_t seed);                          /* seed!(pol, seed) src/MPOPIS.jl:54 */
+/* Per-slot seeds: slot b draws from seeds[b] (B values).  The reference seeds trial k with seed!(pol, seed + k),
+ * src/examples/car_example.jl:187-188; a rank that holds the trials k0, k0+G, k0+2G, ... of a sharded run
+ *  passes {seed + k0, seed + k0 + G, ...} so that all of them stay in ONE resident batch. */
+int  mpopis_seed_slots(mpopis_handle *h, const uint64_t *seeds /* B */);
+/* Σ′ of the proposal MvNormal the LAST executed AIS iteration of the last policy step drew from, per slot:
+ * B x (cs x cs col-major).  (:447,:723,:796 `P = MvNormal(Σ′)`; :cmamppi with N > 1: σ²·Σ′, :550-554; policies
+ * that keep pol.Σ fixed return pol.Σ.)  Lets a caller compare the adapted covariance, which the reference
+ * only exposes indirectly through the next draw. */
+int  mpopis_get_Sigma(mpopis_handle *h, double *Sigma_out /* B*cs*cs */);
 
 /* ---- Level 1: simulate_model(pol, env, E, Σ_inv, U_orig) -> trajectory_cost  (:261-278) ------
  * x0: B*ss (NULL: resident env state); U: B*cs current AIS mean (pol.U); U_orig: B*cs (NULL => U);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "mpopis_abi_version", "mpopis_last_error", "mpopis_create", "mpopis_destroy",
     "mpopis_set_env_params", "mpopis_set_track", "mpopis_set_action_bounds", "mpopis_reset",
     "mpopis_set_state", "mpopis_get_state", "mpopis_set_U", "mpopis_get_U", "mpopis_set_Sigma",
-    "mpopis_seed", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
+    "mpopis_seed", "mpopis_seed_slots", "mpopis_get_Sigma", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
     "mpopis_env_query", "mpopis_get_trajectories", "mpopis_set_state_noise", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
 ]
@@ -77,6 +77,8 @@ def lib():
         L.mpopis_get_U.argtypes = [H, _dp]
         L.mpopis_set_Sigma.argtypes = [H, _dp, C.c_int32]
         L.mpopis_seed.argtypes = [H, C.c_uint64]
+        L.mpopis_seed_slots.argtypes = [H, C.POINTER(C.c_uint64)]
+        L.mpopis_get_Sigma.argtypes = [H, _dp]
         L.mpopis_rollout_costs.argtypes = [H, _dp, _dp, _dp, _dp, _dp, _dp]
         L.mpopis_policy_step.argtypes = [H, C.POINTER(Noise), _dp, _dp, _dp, _dp, _ip, _ip]
         L.mpopis_env_step.argtypes = [H, _dp, _dp]

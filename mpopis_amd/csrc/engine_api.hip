@@ -36,6 +36,11 @@ __global__ void k_bcast_f64(const double* s, double* d, size_t n, int B) {     /
     if (i < n) for (int b = 0; b < B; ++b) d[(size_t)b * n + i] = s[i];
 }
 
+__global__ void k_scaled_copy_f64(const double* s, size_t sstride, const double* scale, double* d, size_t n) {   // d[b][i] = scale[b]*s[b][i]
+    const int b = blockIdx.y; const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n) d[(size_t)b * n + i] = (scale ? scale[b] : 1.0) * s[(size_t)b * sstride + i];
+}
+
 static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
 static void copy_f64(const double* s_, double* d, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_copy_f64, dim3((n + 255) / 256), dim3(256), 0, s, s_, d, n); }
 
@@ -324,6 +329,31 @@ int mpopis_seed(mpopis_handle* h, uint64_t seed) {
     HIPCHK(h, hipMemcpyAsync(h->d_seeds, s.data(), sizeof(uint64_t) * h->B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->mpc_step = 0;
+    return MPOPIS_OK;
+}
+
+int mpopis_seed_slots(mpopis_handle* h, const uint64_t* seeds) {
+    if (!h || !seeds) return MPOPIS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * h->B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->mpc_step = 0;
+    return MPOPIS_OK;
+}
+
+int mpopis_get_Sigma(mpopis_handle* h, double* out) {
+    if (!h || !out) return MPOPIS_ERR_ARG;
+    if (h->cfg.policy == MPOPIS_POL_MPPI) { h->err = "mpopis_get_Sigma: :mppi keeps the as x as pol.Σ (no adaptation)"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int pol = h->cfg.policy;
+    const size_t nn = (size_t)h->cs * h->cs;
+    const bool sigma_fixed = (pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
+    // d_tmpS is scratch outside a policy step
+    const double* scale = (pol == MPOPIS_POL_CMAMPPI && h->N > 1) ? h->d_sig2 : nullptr;     // MvNormal(σ²Σ′) :550-554
+    hipLaunchKernelGGL(k_scaled_copy_f64, dim3((nn + 255) / 256, h->B), dim3(256), 0, h->stream,
+                       sigma_fixed ? h->d_Sigma0 : h->d_Sig, sigma_fixed ? (size_t)0 : nn, scale, h->d_tmpS, nn);
+    HIPCHK(h, hipMemcpyAsync(out, h->d_tmpS, sizeof(double) * h->B * nn, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return MPOPIS_OK;
 }
 

@@ -1,0 +1,184 @@
+"""GPU parity on the EXACT BASELINE.json shapes (C2..C5) and on the large-cs code paths, engine (through
+the C ABI) against the CPU oracle on the same inputs.
+
+What each case reaches inside the engine:
+  C2  :gmppi     K=1024 H=50           diag-Σ sampler, rollout, reweight
+  C3  :cemppi    K=150  H=50 N=10      elite gather (m_elite=30 < cs=100: rank-29 scatter + 1e-8 I), LDS potrf
+  C4  :cmamppi   K=4096 H=50 3 cars    cs=300: k_potrf<false,1024>, multi-row-group trmm, Σ^-½, CMA paths
+  C5  :μΣaismppi K=4096 H=50 N=10      the benched path: MFMA scatter with one-pass mean, potrf<true,512>,
+                                       injected Z AND device RNG (fused Philox k_trmm_LZ_mfma<true,true>)
+  cs=300 :μΣaismppi / :pmcmppi         k_wcov_mfma_partial<16,*> (cs > 112), gather by resampled index
+
+Tolerances: BASELINE.json asks 1e-5 relative on control / per-step cost; held to 1e-7 here (costs relative,
+controls absolute on [-1,1] actions), integers (iterations, resampling indices) bit-exact.  Σ′ is compared
+relative to its largest diagonal entry.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def eng_mod():
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd import engine
+    return engine
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-9)))
+
+
+def sig_err(a, b):
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(np.diag(b))))
+
+
+def cost_err(pol, env, U_orig, cost_dev, ref, tol, worst):
+    """max relative cost deviation over the well-conditioned rollouts.  A rollout that brakes to a standstill enters
+    the reference's sign(Vx) chatter (the 22.5 kN brake force flips sign every Euler sub-step, src/envs/car_racing.jl:311):
+    any two IEEE-754 evaluation orders diverge there, so such rollouts -- identified from the
+    ORACLE's own trajectory, min |Vx| < 1e-3 m/s -- are only counted (must stay below 0.2 % of K)."""
+    rel = np.abs(cost_dev - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)
+    bad = np.where(rel >= tol)[0]
+    if len(bad) == 0:
+        return float(rel.max())
+    # the last iteration rolled out V_k = pol.U' + E_k = U_orig + (E_k + pol.U' - U_orig) = U_orig + ref["E"][:, k]   (γ = 0 here)
+    _, traj = pol.simulate_model(U_orig, ref["E"], log=True)
+    ncars = env.e.ncars
+    vx = np.abs(traj.reshape(traj.shape[0], traj.shape[1], ncars, 8)[:, :, :, 3]).min(axis=(1, 2))
+    stalled = vx < 1e-3
+    assert np.all(stalled[bad]), ("cost deviates on rollouts that never approach Vx = 0", bad[~stalled[bad]][:10], rel[bad][:10])
+    assert len(bad) <= max(2, len(rel) // 500), ("too many chattering rollouts deviate", len(bad))
+    worst["chatter"] = worst.get("chatter", 0) + len(bad)
+    return float(rel[~stalled].max()) if np.any(~stalled) else 0.0
+
+
+def start_states(oracle, track, ncars, B):
+    """slot 0 = reset state; later slots: a mid-lap state harvested from a short seeded closed loop of the oracle
+    (SURVEY 8d "mid-lap state set"), so curved track sections and penalties are exercised."""
+    env = oracle.OracleEnv("car", ncars, track=track)
+    out = [env.state]
+    if B > 1:
+        rng = np.random.default_rng(99)
+        for _ in range(25):
+            a = np.tile([0.05, 0.6], ncars) + 0.1 * rng.standard_normal(2 * ncars)
+            env.step(np.clip(a, -1, 1))
+        for _ in range(B - 1):
+            for _ in range(5):
+                env.step(np.clip(np.tile([0.0, 0.4], ncars) + 0.1 * rng.standard_normal(2 * ncars), -1, 1))
+            out.append(env.state)
+    return np.stack(out)
+
+
+def run_case(eng_mod, oracle, track, kind, ncars, K, T, N, B=2, steps=1, device_rng=False, seed=20240000,
+             sigma_est="mle", tol=TOL, sig_tol=1e-7, check_sigma=True):
+    cs = 2 * ncars * T
+    cov = np.tile([0.0625, 0.1], ncars)
+    Neff = 1 if kind == "gmppi" else N
+    eng = eng_mod.Engine("car", ncars, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8,
+                         sigma_est=sigma_est, cma_sigma=0.75, cov=cov, track=track, seed=seed)
+    x0 = start_states(oracle, track, ncars, B)
+    eng.set_state(x0)
+    envs, pols = [], []
+    for b in range(B):
+        e = oracle.OracleEnv("car", ncars, track=track)
+        e.state = x0[b]
+        p = oracle.OraclePolicy(kind, e, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0,
+                                elite_threshold=0.8, sigma_est=sigma_est, cma_sigma=0.75, nthreads=8)
+        envs.append(e); pols.append(p)
+    rng = np.random.default_rng(1234 + K + cs)
+    worst = dict(cost=0.0, control=0.0, U=0.0, E=0.0, Sigma=0.0, w=0.0)
+    for step in range(steps):
+        if device_rng:
+            Z = np.stack([np.stack([oracle.philox_normals(seed + b + 1, step, n, cs * K).reshape(K, cs) for n in range(Neff)])
+                          for b in range(B)])
+            dd = [[oracle.philox_resample_draws(seed + b + 1, step, n | 0x80000000, K) for n in range(max(Neff - 1, 1))] for b in range(B)]
+            di = np.array([[d[0] for d in row] for row in dd], dtype=np.int32)
+            du = np.array([[d[1] for d in row] for row in dd])
+            got = eng.policy_step(None, want_E=True)
+        else:
+            Z = rng.standard_normal((B, Neff, K, cs))
+            di = rng.integers(0, K, (B, max(Neff - 1, 1), K)).astype(np.int32)
+            du = rng.random((B, max(Neff - 1, 1), K))
+            got = eng.policy_step(Z, di, du, want_E=True)
+        U_dev = eng.get_U()
+        Sig_dev = eng.get_Sigma() if check_sigma else None
+        for b in range(B):
+            U_orig = pols[b].U
+            ref = pols[b](envs[b], Z[b], di[b], du[b])
+            assert ref["status"] == 0
+            assert got["iters_run"][b] == ref["iters_run"], (kind, step, b, got["iters_run"][b], ref["iters_run"])
+            if kind == "pmcmppi":
+                n_it = ref["iters_run"]
+                assert np.array_equal(got["res_idx0"][b][:n_it - 1], ref["res_idx0"][:n_it - 1])          # bit-exact
+            worst["cost"] = max(worst["cost"], cost_err(pols[b], envs[b], U_orig, got["cost"][b], ref, tol, worst))
+            worst["w"] = max(worst["w"], float(np.max(np.abs(got["weights"][b] - ref["weights"]))))
+            worst["E"] = max(worst["E"], float(np.max(np.abs(got["E"][b].T - ref["E"]))))
+            worst["control"] = max(worst["control"], float(np.max(np.abs(got["control"][b] - ref["control"]))))
+            worst["U"] = max(worst["U"], float(np.max(np.abs(U_dev[b] - pols[b].U))))
+            if check_sigma:
+                worst["Sigma"] = max(worst["Sigma"], sig_err(Sig_dev[b], ref["Sigma_last"]))
+    eng.close()
+    print("\n[parity] %s ncars=%d K=%d T=%d N=%d rng=%s est=%s: %s" % (
+        kind, ncars, K, T, N, "device" if device_rng else "injected", sigma_est,
+        " ".join("%s=%.2e" % kv for kv in worst.items())))
+    assert worst["cost"] < tol, worst
+    assert worst["control"] < tol, worst
+    assert worst["U"] < tol, worst
+    assert worst["E"] < tol, worst
+    assert worst["w"] < tol, worst
+    assert worst["Sigma"] < sig_tol, worst
+    return worst
+
+
+def test_C2_gmppi_K1024_H50(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "gmppi", 1, 1024, 50, 1, steps=2)
+
+
+def test_C2_gmppi_K1024_H50_device_rng(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "gmppi", 1, 1024, 50, 1, steps=2, device_rng=True)
+
+
+@pytest.mark.parametrize("est", ["mle", "ss"])
+def test_C3_cemppi_K150_H50_N10(eng_mod, oracle, track, est):
+    run_case(eng_mod, oracle, track, "cemppi", 1, 150, 50, 10, steps=2, sigma_est=est)
+
+
+def test_C3_cemppi_device_rng(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "cemppi", 1, 150, 50, 10, steps=2, device_rng=True, sigma_est="ss")
+
+
+def test_C4_cmamppi_3car_K4096_H50(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "cmamppi", 3, 4096, 50, 3, steps=1)
+
+
+def test_C4_cmamppi_3car_device_rng_N4(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "cmamppi", 3, 4096, 50, 4, B=1, steps=2, device_rng=True)
+
+
+def test_C5_musigma_K4096_H50_N10_injected(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "musigmaaismppi", 1, 4096, 50, 10, steps=1)
+
+
+def test_C5_musigma_K4096_H50_N10_device_rng(eng_mod, oracle, track):
+    """The benched path: fused Philox sampler k_trmm_LZ_mfma<true,true> + one-pass-mean MFMA scatter."""
+    run_case(eng_mod, oracle, track, "musigmaaismppi", 1, 4096, 50, 10, steps=2, device_rng=True)
+
+
+@pytest.mark.parametrize("kind", ["musigmaaismppi", "pmcmppi"])
+def test_cs300_scatter_and_global_potrf(eng_mod, oracle, track, kind):
+    run_case(eng_mod, oracle, track, kind, 3, 1024, 50, 3, steps=1)
+
+
+def test_cs300_pmcmppi_device_rng_K4096(eng_mod, oracle, track):
+    run_case(eng_mod, oracle, track, "pmcmppi", 3, 4096, 50, 3, B=1, steps=1, device_rng=True)
+
+
+@pytest.mark.parametrize("kind", ["muaismppi", "imppi", "pmcmppi"])
+def test_full_size_other_policies_1car(eng_mod, oracle, track, kind):
+    run_case(eng_mod, oracle, track, kind, 1, 4096, 50, 4, steps=1)
