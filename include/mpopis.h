@@ -21,6 +21,9 @@
  *       MPOPIS_ERR_NOT_PD  (-2) PosDefException from MvNormal(Sigma')   :447,551,723,796
  *       MPOPIS_ERR_ACTION  (-3) "Action is not in action space" / NaN   src/envs/car_racing.jl:239
  *       MPOPIS_ERR_HIP     (-4) HIP runtime failure / no device
+ *       MPOPIS_ERR_NUMERIC (-5) :cmamppi only: the iterative Σ^-0.5 δw (:580-581) did not reach 1e-13 within its step
+ *                               budget (cond(Σ) far outside what CMA adaptation produces); the reference's eigen-based
+ *                               Σ^-0.5 has no such limit, so this is reported instead of returning a wrong control
  *     mpopis_last_error() returns a human readable message for the last failure.
  *   - a handle is not thread-safe; distinct handles are independent (own HIP stream).
  */
@@ -33,7 +36,7 @@ extern "C" {
 
 #define MPOPIS_ABI_VERSION 1
 
-enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4 };
+enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };
 
 /* env kinds: RL.jl MountainCarEnv(continuous=true) + src/examples/mountaincar_example.jl:4-22;
  * CarRacingEnv src/envs/car_racing.jl (num_cars==1) / MultiCarRacingEnv src/envs/multi-car_racing.jl;
@@ -174,6 +177,26 @@ int  mpopis_get_trajectories(mpopis_handle *h, double *out);
 int  mpopis_set_state_noise(mpopis_handle *h, double sigma_x, double sigma_y, double sigma_psi);
 int  mpopis_run_trials(mpopis_handle *h, int32_t num_steps, int32_t laps, double *records /* B*16 */,
                        double *actions /* NULL or B x (num_steps+1) x as */);
+
+/* ---- the one collective: summary records to rank 0 over RCCL/xGMI ---------------------
+ * Trials shard over GPUs at trial granularity: trial k -> rank (k-1) mod G (`for k in 1:num_trials`,
+ * src/examples/car_example.jl:170, has no cross-trial dependency), each rank runs its trials as one resident batch
+ * (mpopis_seed_slots + mpopis_run_trials) and nothing is exchanged until the per-trial records
+ * (src/examples/car_example.jl:144-155,287-302) are gathered for the AVE/STD/MED/... table (:328-410).
+ *   mpopis_comm_unique_id : rank 0 creates the 128-byte RCCL id; the host distributes it (MPI / Distributed.jl / a file)
+ *   mpopis_comm_init      : every rank, same id; binds an RCCL communicator to the handle's device and stream
+ *                           (world == 1 with id == NULL: no RCCL is loaded, the gather is a copy;
+ *                           world == 1 with an id: a real one-rank RCCL communicator)
+ *   mpopis_gather_summary : every rank passes its n_local records (rows of MPOPIS_RECORD_LEN doubles); n_max = the largest
+ *                           n_local over ranks (ceil(num_trials / world)).  Rank 0 receives out[world][n_max][RECORD_LEN]
+ *                           and counts[world] (rows valid per rank); other ranks may pass NULL for both.
+ * librccl is bound with dlopen at the first comm call; single-GPU users never load it. */
+#define MPOPIS_COMM_ID_BYTES 128
+int  mpopis_comm_unique_id(char *id128);
+int  mpopis_comm_init(mpopis_handle *h, const char *id128, int32_t rank, int32_t world);
+int  mpopis_gather_summary(mpopis_handle *h, const double *records, int32_t n_local, int32_t n_max,
+                           double *out, int32_t *counts);
+int  mpopis_comm_destroy(mpopis_handle *h);
 
 /* ---- measurement hooks (bench.py; HIP events on the engine's own stream) ----------------------- */
 int  mpopis_timing_enable(mpopis_handle *h, int32_t on);   /* 0 off; 1 every kernel class; else a mask: bit (i + 1) = class i of

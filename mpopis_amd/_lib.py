@@ -15,7 +15,7 @@ ENV_IDS = {"mountaincar": ENV_MOUNTAINCAR, "car": ENV_CAR, "cartpole": ENV_CARTP
 POLICY_IDS = {"mppi": 0, "gmppi": 1, "imppi": 2, "cemppi": 3, "cmamppi": 4,
               "μaismppi": 5, "muaismppi": 5, "μΣaismppi": 6, "musigmaaismppi": 6, "pmcmppi": 7}
 SIGMA_EST_IDS = {"mle": 0, "ss": 1, "lw": 2, "rblw": 3, "oas": 4}
-ERR_ARG, ERR_NOT_PD, ERR_ACTION, ERR_HIP = -1, -2, -3, -4
+ERR_ARG, ERR_NOT_PD, ERR_ACTION, ERR_HIP, ERR_NUMERIC = -1, -2, -3, -4, -5
 RECORD_LEN = 16
 
 # every symbol include/mpopis.h declares (checked by tests/test_abi.py without a GPU)
@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "mpopis_seed", "mpopis_seed_slots", "mpopis_get_Sigma", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
     "mpopis_env_query", "mpopis_get_trajectories", "mpopis_set_state_noise", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
+    "mpopis_comm_unique_id", "mpopis_comm_init", "mpopis_gather_summary", "mpopis_comm_destroy",
 ]
 
 
@@ -90,6 +91,10 @@ def lib():
         L.mpopis_timing_read.argtypes = [H, C.c_char_p, C.c_int32, _dp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.mpopis_timing_reset.argtypes = [H]
         L.mpopis_bench_policy_steps.argtypes = [H, C.c_int32, _dp, _dp]
+        L.mpopis_comm_unique_id.argtypes = [C.c_char_p]
+        L.mpopis_comm_init.argtypes = [H, C.c_char_p, C.c_int32, C.c_int32]
+        L.mpopis_gather_summary.argtypes = [H, _dp, C.c_int32, C.c_int32, _dp, _ip]
+        L.mpopis_comm_destroy.argtypes = [H]
         _lib = L
     return _lib
 

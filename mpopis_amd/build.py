@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmpopis_hip.so")
-SOURCES = ["engine_api.hip", "engine_ais.hip", "engine_harness.hip", "kernels_rollout.hip", "kernels_reweight.hip",
-           "kernels_sample.hip", "kernels_linalg.hip", "kernels_select.hip", "kernels_cma.hip", "kernels_mfma.hip"]
+SOURCES = ["engine_api.hip", "engine_ais.hip", "engine_harness.hip", "engine_comm.hip", "kernels_rollout.hip", "kernels_reweight.hip",
+           "kernels_sample.hip", "kernels_linalg.hip", "kernels_select.hip", "kernels_cma.hip", "kernels_invsqrt.hip", "kernels_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 
@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc compilation failed")
     if procs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         subprocess.check_call(cmd)
     return LIB
 

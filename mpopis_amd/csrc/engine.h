@@ -14,12 +14,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/mpopis.h"
 #include "car_dynamics.h"
 
 namespace mpopis {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a process that keeps one handle per GPU
+//  must configure each large-LDS kernel once on every device it launches on.
+// `seen` = the call site's static bit mask of configured device ordinals (atomic: handles may live on different threads).
+inline void ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long long>& seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (seen.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    seen.fetch_or(bit, std::memory_order_relaxed);
+}
 
 constexpr int kMaxCars = 4;
 constexpr int kMaxAs = 2 * kMaxCars;
@@ -104,10 +117,6 @@ void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma,
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s);
-void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, int n, double alpha, double beta,
-                          unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s);
-void launch_gemm_sym_mfma_pair(const double* A1, const double* A2, const double* Bm, double* D1, double* D2, int B, int n,
-                               const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
@@ -132,10 +141,13 @@ void launch_alias_sample(const double* accept, const int32_t* alias, const int32
                          int32_t* out, int32_t* log, size_t log_stride, int B, int K, const int* active, hipStream_t s);
 
 // kernels_cma.hip
-void launch_inv_sqrt_spd(const double* A, double* C, double* Y0, double* Y1, double* Z0, double* Z1, double* Tm, double* cnorm,
-                         unsigned long long* resid, int B, int n, int iters, const int* active, hipStream_t s);
+// kernels_invsqrt.hip: y = A^-1/2 b (Lanczos + quadrature) and fro = tr(A^-1) = scale * ||L^-1||_F^2 with L = chol(scale * A)
+size_t invsqrt_workspace_doubles(int B, int n);
+int invsqrt_max_n();
+void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
+                        double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);
 void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, int cs, int B, hipStream_t s);
-void launch_cma_paths(const double* C, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
+void launch_cma_paths(const double* Cdw, const double* fro, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
                       double* sig2, int B, int cs, int K, int n_iter, const double* consts7, int m_elite, const int* active, hipStream_t s);
 void launch_cma_sigma_update(double* Sig, const double* scal, const double* vec, int B, int cs, const double* consts7, int m_elite,
                              const int* active, hipStream_t s);

@@ -122,8 +122,10 @@ int mpopis_handle::ais_update(int n, bool injected) {
         time_begin(4);
         double* dw = d_cma_vec + 2 * (size_t)cs;                                              // δw slot of slot 0; stride 3cs
         launch_gather_mean_strided(d_E, d_order, d_cma_ws, dw, (size_t)3 * cs, B, cs, K, m_elite, d_active, stream);   // :573-576
-        launch_inv_sqrt_spd(d_Sig, d_C, d_Y0, d_Y1, d_Z0, d_Z1, d_Tm, d_cnorm, d_resid, B, cs, kNsIters, d_active, stream);   // C = Σ^-0.5 :580
-        launch_cma_paths(d_C, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
+        // C = Σ^-0.5 (:580) is only consumed as C*δw (:581) and ||C||_F (:593): neither needs the matrix.  d_L = chol(σ²Σ) is the
+        // factor this iteration sampled from (same Σ: the update :598 comes after), so tr(Σ^-1) = σ² ||L^-1||_F²
+        launch_invsqrt_vec(d_Sig, d_L, (size_t)cs * cs, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream);
+        launch_cma_paths(d_Cdw, d_fro, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
         launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);
         time_end();
         return MPOPIS_OK;

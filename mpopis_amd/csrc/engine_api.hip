@@ -71,6 +71,7 @@ static int sync_status(mpopis_handle* h) {
     for (int b = 0; b < h->B; ++b) st = std::min(st, h->h_status[b]);
     if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
     else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
+    else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
     return st;
 }
 
@@ -105,6 +106,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (car && (cfg->num_cars < 1 || cfg->num_cars > kMaxCars)) { g_create_error = "num_cars must be 1..4"; return MPOPIS_ERR_ARG; }
     if (cfg->policy < MPOPIS_POL_MPPI || cfg->policy > MPOPIS_POL_PMCMPPI) { g_create_error = "No policy_type of that kind"; return MPOPIS_ERR_ARG; }
     if (cfg->num_samples < 1 || cfg->horizon < 1 || cfg->batch < 1) { g_create_error = "num_samples, horizon, batch must be >= 1"; return MPOPIS_ERR_ARG; }
+    if (cfg->policy == MPOPIS_POL_CMAMPPI && (car ? 2 * cfg->num_cars : 1) * cfg->horizon > invsqrt_max_n()) { g_create_error = "cmamppi: control space too large for the on-chip Σ^-0.5 δw kernel"; return MPOPIS_ERR_ARG; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (the engine has no CPU fallback)"; return MPOPIS_ERR_HIP; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "bad device ordinal"; return MPOPIS_ERR_ARG; }
@@ -146,10 +148,9 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
     if (cfg->policy == MPOPIS_POL_CMAMPPI) {
         rc |= dalloc(h, &h->d_cma_scal, (size_t)B * 8); rc |= dalloc(h, &h->d_cma_vec, (size_t)B * 3 * cs); rc |= dalloc(h, &h->d_sig2, B);
-        rc |= dalloc(h, &h->d_cma_ws, (size_t)K); rc |= dalloc(h, &h->d_cnorm, B);
-        rc |= dalloc(h, &h->d_C, (size_t)B * nn); rc |= dalloc(h, &h->d_Y0, (size_t)B * nn); rc |= dalloc(h, &h->d_Y1, (size_t)B * nn);
-        rc |= dalloc(h, &h->d_Z0, (size_t)B * nn); rc |= dalloc(h, &h->d_Z1, (size_t)B * nn); rc |= dalloc(h, &h->d_Tm, (size_t)B * nn);
-        rc |= dalloc(h, &h->d_resid, (size_t)(mpopis_handle::kNsIters + 1) * B);
+        rc |= dalloc(h, &h->d_cma_ws, (size_t)K);
+        rc |= dalloc(h, &h->d_lanV, invsqrt_workspace_doubles(B, cs)); rc |= dalloc(h, &h->d_Cdw, (size_t)B * cs);
+        rc |= dalloc(h, &h->d_fro_part, (size_t)B * ((cs + 15) / 16)); rc |= dalloc(h, &h->d_fro, B); rc |= dalloc(h, &h->d_lan_m, B);
     }
     if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
@@ -176,6 +177,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
 
 void mpopis_destroy(mpopis_handle* h) {
     if (!h) return;
+    if (h->comm) (void)mpopis_comm_destroy(h);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);

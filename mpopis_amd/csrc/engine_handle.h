@@ -32,14 +32,15 @@ struct mpopis_handle {
     int m_elite = 0;
     double cma_consts[7] = {0, 0, 0, 0, 0, 0, 0};    // mu_eff, cσ, dσ, cΣ, c1, cμ, E
     std::vector<double> cma_ws_host;
-    double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr, *d_cnorm = nullptr;
-    double *d_C = nullptr, *d_Y0 = nullptr, *d_Y1 = nullptr, *d_Z0 = nullptr, *d_Z1 = nullptr, *d_Tm = nullptr;
-    unsigned long long* d_resid = nullptr;
-    static constexpr int kNsIters = 16;
+    double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr;
+    double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
+    int* d_lan_m = nullptr;                                                                // Lanczos steps taken per slot (diagnostic)
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
     // Level-3 harness
     double* d_hs = nullptr; int* d_alive = nullptr; const int* alive_gate = nullptr; bool status_sticky = false;
     double noise_sx = 0.0, noise_sy = 0.0, noise_spsi = 0.0;   // simulate_car_racing state noise (car_example.jl:224-236)
+    // RCCL communicator for the summary gather (engine_comm.hip); world == 1 needs none
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     // bookkeeping
     uint64_t mpc_step = 0;
     std::vector<int> h_status;

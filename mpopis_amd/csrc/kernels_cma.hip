@@ -3,86 +3,11 @@
 //   pσ, σ, hσ, pΣ updates            :581-586
 //   temp_sum (scalar, quirk)        :588-596
 //   Σ update + triu symmetrisation   :598-599
-// Σ^-0.5 is computed with the coupled Newton-Schulz iteration (Higham, "Functions of Matrices", eq. 6.35)
-//   Y0 = A/c, Z0 = I;  T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;   Y -> (A/c)^1/2, Z -> (A/c)^-1/2
-// which is all GEMM (batched FP64 on the matrix cores, kernels_mfma.hip; every iterate is a polynomial in A, hence
-// symmetric) and converges quadratically for SPD A once c >= λmax (c = ||A||_inf).  It reaches the same matrix the
-// eigen path does, to ~cond(A)*eps.
+// The matrix C itself is never formed: the reference only consumes the vector C*δw and the scalar ||C||_F (see
+// kernels_invsqrt.hip, which delivers both); this file holds the path / step-size / covariance updates.
 #include "engine.h"
 
 namespace mpopis {
-
-__global__ void k_ns_resid_init(unsigned long long* r, int B, size_t n) {
-    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (i < n) r[i] = (i < (size_t)B) ? 0x7FF0000000000000ull : 0ull;
-}
-
-// c[b] = ||A||_inf (A symmetric: max column abs sum; one wave per column, coalesced)
-__global__ void __launch_bounds__(1024) k_ns_norm(const double* __restrict__ A, double* cnorm, int n, const int* active) {
-    const int b = blockIdx.x;
-    if (active && !active[b]) return;
-    __shared__ double sh[16];
-    const size_t off = (size_t)b * n * n;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double mx = 0.0;
-    for (int j = wv; j < n; j += 16) {
-        double s = 0.0;
-        for (int i = lane; i < n; i += 64) s += fabs(A[off + i + (size_t)j * n]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        mx = fmax(mx, s);
-    }
-    if (lane == 0) sh[wv] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) { double c = 0.0; for (int q = 0; q < 16; ++q) c = fmax(c, sh[q]); cnorm[b] = c; }
-}
-// Y0 = A / c ; Z0 = I
-__global__ void __launch_bounds__(256) k_ns_init(const double* __restrict__ A, double* __restrict__ Y, double* __restrict__ Z, const double* cnorm,
-                                                 int n, const int* active) {
-    const int b = blockIdx.z, j = blockIdx.y;
-    if (active && !active[b]) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t e = (size_t)b * n * n + i + (size_t)j * n;
-    Y[e] = A[e] * (1.0 / cnorm[b]);
-    Z[e] = (i == j) ? 1.0 : 0.0;
-}
-
-// C = Z / sqrt(c)   (Z ~ (A/c)^-1/2).  Z lives in Z0 (even iterations) or Z1 (odd): the slot froze at the first
-// iteration `it` whose incoming residual was below tol; if it never converged the last iterate is used.
-__global__ void __launch_bounds__(256) k_ns_finish(const double* __restrict__ Z0, const double* __restrict__ Z1, const double* cnorm,
-                                                   const unsigned long long* resid, int iters, int B, double tol,
-                                                   double* __restrict__ C, int n, const int* active) {
-    const int b = blockIdx.y;
-    if (active && !active[b]) return;
-    int it = 0;
-    while (it < iters && !(__longlong_as_double((long long)resid[(size_t)it * B + b]) < tol)) ++it;
-    const double* Z = (it & 1) ? Z1 : Z0;
-    const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;
-    if (e < (size_t)n * n) C[(size_t)b * n * n + e] = Z[(size_t)b * n * n + e] / sqrt(cnorm[b]);
-}
-
-void launch_inv_sqrt_spd(const double* A, double* C, double* Y0, double* Y1, double* Z0, double* Z1, double* Tm, double* cnorm,
-                         unsigned long long* resid /* [iters+1][B] zeroed by this call */, int B, int n, int iters,
-                         const int* active, hipStream_t s) {
-    // resid[it][b]: max|I - ZY| seen by iteration it (ordered uint64 bits); row 0 = +inf ("not converged")
-    hipLaunchKernelGGL(k_ns_resid_init, dim3(((size_t)(iters + 1) * B + 255) / 256), dim3(256), 0, s, resid, B, (size_t)(iters + 1) * B);
-    hipLaunchKernelGGL(k_ns_norm, dim3(B), dim3(1024), 0, s, A, cnorm, n, active);
-    hipLaunchKernelGGL(k_ns_init, dim3((n + 255) / 256, n, B), dim3(256), 0, s, A, Y0, Z0, cnorm, n, active);
-    const double tol = 64.0 * n * 1.1e-16;                     // rounding floor of max|I - ZY| grows with n
-    double *Yc = Y0, *Yn = Y1, *Zc = Z0, *Zn = Z1;
-    for (int it = 0; it < iters; ++it) {
-        unsigned long long* rprev = resid + (size_t)it * B;
-        unsigned long long* rnew = resid + (size_t)(it + 1) * B;
-        // T = 1.5 I - 0.5 Z Y  (+ residual max|I - ZY|)
-        launch_gemm_sym_mfma(Zc, Yc, Tm, B, n, -0.5, 1.5, rnew, rprev, tol, active, s);
-        // Y' = Y T ; Z' = T Z   (slots freeze once converged)
-        // (T is a polynomial in Z Y, the iterates are symmetric and commute: T Z = Z T, so both products share the right operand)
-        launch_gemm_sym_mfma_pair(Yc, Zc, Tm, Yn, Zn, B, n, rprev, tol, active, s);
-        std::swap(Yc, Yn); std::swap(Zc, Zn);
-    }
-    hipLaunchKernelGGL(k_ns_finish, dim3(((size_t)n * n + 255) / 256, B), dim3(256), 0, s, Z0, Z1, cnorm, resid, iters, B, tol, C, n, active);
-}
 
 // Per-slot CMA scalars (d_cma_scal[b][8]): [0] σ  [1] temp_sum  [2] hσ  [3] ||pσ||  [4] ||C||_F²
 // vectors (d_cma_vec[b][3*cs]): pσ | pΣ | δw.   sig2[b] = σ² (scale of the next proposal, :551).
@@ -96,10 +21,9 @@ __global__ void __launch_bounds__(256) k_cma_begin(double* scal, double* vec, do
 
 // δw given (gather_mean with cw); this kernel: pol.U += σ δw; pσ; σ; hσ; pΣ; temp_sum
 constexpr int kCmaThreads = 1024, kCmaWaves = kCmaThreads / 64;
-__global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restrict__ C, const double* __restrict__ E, const int32_t* __restrict__ order,
+__global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restrict__ Cdw, const double* __restrict__ froC, const double* __restrict__ E, const int32_t* __restrict__ order,
                                                    const double* __restrict__ ws, double* Ucur, double* scal, double* vec, double* sig2,
                                                    int cs, int K, int n_iter, CmaConsts cc, const int* active) {
-    extern __shared__ __attribute__((aligned(16))) double part_v[];          // [kCmaWaves][cs] partial C*δw
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[kCmaWaves];
@@ -114,37 +38,19 @@ __global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restr
         for (int w = 0; w < kCmaWaves; ++w) t += sh[w];
         return t;
     };
-    const size_t nn = (size_t)cs * cs;
-    const double* Cb = C + (size_t)b * nn;
+    const double* yb = Cdw + (size_t)b * cs;                  // Σ^-0.5 δw
     double* ps = vec + (size_t)b * 3 * cs; double* pS = ps + cs; double* dw = pS + cs;
     double* Ub = Ucur + (size_t)b * cs;
     const double sigma_old = scal[b * 8 + 0];
     const double sc = sqrt(cc.c_sigma * (2 - cc.c_sigma) * cc.mu_eff);
-    double nps2 = 0.0, fro = 0.0;
-    // C*δw and ||C||_F²: lanes run along rows i (coalesced column reads), the 16 waves split the columns j
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int jper = (cs + kCmaWaves - 1) / kCmaWaves, j0 = wv * jper, j1 = min(cs, j0 + jper);
-        for (int rc = 0; rc < cs; rc += 64) {
-            const int i = rc + lane;
-            double v = 0.0;
-            if (i < cs) {
-                for (int j = j0; j < j1; ++j) { const double cij = Cb[i + (size_t)j * cs]; v = fma(sc * cij, dw[j], v); fro = fma(cij, cij, fro); }
-                part_v[(size_t)wv * cs + i] = v;
-            }
-        }
-    }
-    __syncthreads();
+    double nps2 = 0.0;
+    const double fro = froC[b];                               // ||C||_F² = tr(Σ^-1)
     for (int i = threadIdx.x; i < cs; i += kCmaThreads) {
         Ub[i] += sigma_old * dw[i];                                                        // :577
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < kCmaWaves; ++w) v += part_v[(size_t)w * cs + i];
-        const double pn = (1 - cc.c_sigma) * ps[i] + v;                                    // :581
+        const double pn = (1 - cc.c_sigma) * ps[i] + sc * yb[i];                           // :581
         ps[i] = pn; nps2 = fma(pn, pn, nps2);
     }
     nps2 = block_sum(nps2);
-    fro = block_sum(fro);
     const double nps = sqrt(nps2);
     const double sigma_new = sigma_old * exp(cc.c_sigma / cc.d_sigma * (nps / cc.E_cma - 1));   // :582
     const int h_sigma = (nps / sqrt(1 - pow(1 - cc.c_sigma, 2.0 * n_iter)) < (1.4 + 2.0 / (cs + 1)) * cc.E_cma) ? 1 : 0;   // :585
@@ -191,10 +97,10 @@ __global__ void __launch_bounds__(256) k_cma_sigma_update(double* Sig, const dou
 void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, int cs, int B, hipStream_t s) {
     hipLaunchKernelGGL(k_cma_begin, dim3(B), dim3(256), 0, s, scal, vec, sig2, sigma0, cs, B);
 }
-void launch_cma_paths(const double* C, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
+void launch_cma_paths(const double* Cdw, const double* fro, const double* E, const int32_t* order, const double* ws, double* Ucur, double* scal, double* vec,
                       double* sig2, int B, int cs, int K, int n_iter, const double* consts7, int m_elite, const int* active, hipStream_t s) {
     CmaConsts cc{consts7[0], consts7[1], consts7[2], consts7[3], consts7[4], consts7[5], consts7[6], m_elite};
-    hipLaunchKernelGGL(k_cma_paths, dim3(B), dim3(kCmaThreads), (size_t)kCmaWaves * cs * sizeof(double), s, C, E, order, ws, Ucur, scal, vec, sig2, cs, K, n_iter, cc, active);
+    hipLaunchKernelGGL(k_cma_paths, dim3(B), dim3(kCmaThreads), 0, s, Cdw, fro, E, order, ws, Ucur, scal, vec, sig2, cs, K, n_iter, cc, active);
 }
 void launch_cma_sigma_update(double* Sig, const double* scal, const double* vec, int B, int cs, const double* consts7, int m_elite,
                              const int* active, hipStream_t s) {

@@ -209,13 +209,13 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
     const int npad = (n + kNB - 1) / kNB * kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_potrf<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+        static std::atomic<unsigned long long> seen{0};
+        ensure_dyn_lds((const void*)k_potrf<true, 512>, 150 * 1024, seen);
         hipLaunchKernelGGL((k_potrf<true, 512>), dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
         const size_t strip = ((size_t)n * (kNB + 1) + kNB * (kNB + 1)) * sizeof(double);     // panel strip + diagonal block
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)k_potrf<false, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr2 = true; }
+        static std::atomic<unsigned long long> seen2{0};
+        ensure_dyn_lds((const void*)k_potrf<false, 1024>, 150 * 1024, seen2);
         hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), strip, s, A, Astride, L, n, n, scale, status, active);
     }
 }

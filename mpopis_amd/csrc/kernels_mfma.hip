@@ -23,33 +23,20 @@ constexpr int kTrmmTiles = 8;       // row tiles (of 16) per workgroup pass => 3
 // current chunk's MFMAs.
 constexpr int kTrmmRows = kTrmmTiles * 16;          // 128 rows per pass
 constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 32) doubles: conflict-free operand reads
-// TRI = true : L lower triangular (the sampler's E = L*Z).
-// TRI = false: general product D = alpha*(L*Z) + beta*I with K == n (Newton-Schulz step on symmetric iterates, where
-//              row-major == column-major), optional residual max|I - L*Z| (ordered-uint64 atomicMax) and freeze-on-
-//              convergence: a slot whose previous residual is below tol does nothing.
-// RNG = true (with TRI): Z is never materialised -- every wave draws the 16 x 16 block of standard normals it needs for the
+// L is lower triangular (the sampler's E = L*Z): row tiles above a chunk's block row are skipped.
+// RNG = true: Z is never materialised -- every wave draws the 16 x 16 block of standard normals it needs for the
 //              current chunk from the Philox streams (same counters as k_sample_normal_pair, i.e. the same numbers), two
 //              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
 //              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
 struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; };
-// optional second (left operand, output) pair sharing the right operand: grid.z = 2 * nbatch, z >= nbatch works on (L2, E2)
-struct PairArgs { const double* L2; double* E2; int nbatch; };
 // 4 waves per SIMD (128 VGPRs; the LDS panel allows 4 workgroups per CU): measured 5 % faster than the default 3 for the fused
 // sampler (Philox / Box-Muller VALU work of one wave fills the slots in which another waits on the matrix cores)
-template <bool TRI, bool RNG>
+template <bool RNG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
-                                                      double* __restrict__ E, int n, int K, const int* active,
-                                                      double alpha, double beta, unsigned long long* resid,
-                                                      const unsigned long long* resid_prev, double tol, RngArgs rng, PairArgs pair) {
+                                                      double* __restrict__ E, int n, int K, const int* active, RngArgs rng) {
     __shared__ double Ls[2][16][kTrmmLd];
-    const bool second = pair.nbatch > 0 && (int)blockIdx.z >= pair.nbatch;
-    const int b = second ? blockIdx.z - pair.nbatch : blockIdx.z;
-    if (second) { L = pair.L2; E = pair.E2; }
+    const int b = blockIdx.z;
     if (active && !active[b]) return;
-    if (!TRI && resid_prev && __longlong_as_double((long long)resid_prev[b]) < tol) {
-        if (resid && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) resid[b] = resid_prev[b];
-        return;
-    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wv) * 16;
     const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
@@ -64,7 +51,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     v4f64 acc[kTrmmTiles];
 #pragma unroll
     for (int t = 0; t < kTrmmTiles; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int jend = TRI ? min(n, (t0 + nt) * 16) : n;         // lower triangular: j <= i
+    const int jend = min(n, (t0 + nt) * 16);                   // lower triangular: j <= i
     // staging map: thread -> row si of the pass, columns sj + 2u (u < 8) of the chunk
     const int si = threadIdx.x & (kTrmmRows - 1), sj = threadIdx.x >> 7;
     const int gi = t0 * 16 + si, gic = min(gi, n - 1);
@@ -100,16 +87,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int jc = sj + 2 * u, j = j0 + jc;
-            Ls[buf][(jc & 3) * 4 + (jc >> 2)][si] = (gi < n && j < n && (!TRI || j <= gi)) ? lreg[u] : 0.0;
+            Ls[buf][(jc & 3) * 4 + (jc >> 2)][si] = (gi < n && j < n && j <= gi) ? lreg[u] : 0.0;
         }
         double bc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * lk + q < n) ? bz[q] : 0.0;
         __syncthreads();
         if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
-        // TRI: row tiles above the chunk's block row are all zero.  !TRI: the product of the (commuting) symmetric operands is
-        // symmetric, so a wave only computes the tiles on or below the diagonal of its 16 columns and mirrors them on store
-        const int tfirst = TRI ? max(0, j0 / 16 - t0) : max(0, (k0 >> 4) - t0);
+        const int tfirst = max(0, j0 / 16 - t0);                // row tiles above the chunk's block row are all zero
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
             if (t >= tfirst && t < nt) {                        // wave-uniform
@@ -119,7 +104,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
         }
     }
-    double rmax = 0.0;
     if (wave_on && k0 + li < K) {
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
@@ -127,57 +111,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = (t0 + t) * 16 + lk + 4 * r;
-                    if (i < n) {
-                        if (TRI) Eb[(size_t)i * K + k0 + li] = acc[t][r];
-                        else if (t0 + t >= (k0 >> 4)) {
-                            const double ab = acc[t][r], id = (i == k0 + li) ? 1.0 : 0.0;
-                            rmax = fmax(rmax, fabs(id - ab));
-                            const double v = alpha * ab + id * beta;
-                            Eb[(size_t)i * K + k0 + li] = v;
-                            if (t0 + t > (k0 >> 4)) Eb[(size_t)(k0 + li) * K + i] = v;         // mirror of a strictly-lower tile
-                        }
-                    }
+                    if (i < n) Eb[(size_t)i * K + k0 + li] = acc[t][r];
                 }
             }
         }
-    }
-    if (!TRI && resid) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
-        if (lane == 0) atomicMax(&resid[b], (unsigned long long)__double_as_longlong(rmax));
     }
 }
 
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<true, false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{nullptr, 0, 0}, PairArgs{nullptr, nullptr, 0});
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
+                       RngArgs{nullptr, 0, 0});
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
     if ((n & 1) || nt > kTrmmTiles) return false;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<true, true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0.0, RngArgs{seeds, slo, shi}, PairArgs{nullptr, nullptr, 0});
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
+                       RngArgs{seeds, slo, shi});
     return true;
 }
-// D = alpha*(A*Bm) + beta*I for symmetric n x n operands (batched, stride n*n), see k_trmm_LZ_mfma<false>
-void launch_gemm_sym_mfma(const double* A, const double* Bm, double* D, int B, int n, double alpha, double beta,
-                          unsigned long long* resid, const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
-    const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<false, false>), dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, A, (size_t)n * n, Bm, D, n, n, active,
-                       alpha, beta, resid, resid_prev, tol, RngArgs{nullptr, 0, 0}, PairArgs{nullptr, nullptr, 0});
-}
-
-// D1 = A1*Bm and D2 = A2*Bm in ONE launch (same right operand; Newton-Schulz: Y' = Y T, Z' = Z T)
-void launch_gemm_sym_mfma_pair(const double* A1, const double* A2, const double* Bm, double* D1, double* D2, int B, int n,
-                               const unsigned long long* resid_prev, double tol, const int* active, hipStream_t s) {
-    const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<false, false>), dim3((n + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, 2 * B), dim3(256), 0, s, A1, (size_t)n * n, Bm, D1, n, n, active,
-                       1.0, 0.0, (unsigned long long*)nullptr, resid_prev, tol, RngArgs{nullptr, 0, 0}, PairArgs{A2, D2, B});
-}
-
 // ---------------------------------------------------------------------------------------------
 // Scatter matrix partials.  A workgroup (4 waves) owns a group of <= 28 lower-triangular 16x16 tile pairs
 // (7 per wave) and one K split; it streams its k range in chunks staged through LDS as centred rows
@@ -441,14 +395,11 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
     const size_t lds = ((size_t)nt * 16 * (kc + 1) + kc) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_wcov_mfma_partial<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> seen[4];
+    ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, false>, 96 * 1024, seen[0]);
+    ensure_dyn_lds((const void*)k_wcov_mfma_partial<16, false>, 96 * 1024, seen[1]);
+    ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, true>, 96 * 1024, seen[2]);
+    ensure_dyn_lds((const void*)k_wcov_mfma_partial<16, true>, 96 * 1024, seen[3]);
     const dim3 grid(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B);
     if (rscale) {
         if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);

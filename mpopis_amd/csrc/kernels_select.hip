@@ -39,8 +39,8 @@ void launch_sortperm(const double* cost, int32_t* order, int B, int K, const int
     int n = 1;
     while (n < K) n <<= 1;
     const size_t bytes = (size_t)n * (sizeof(double) + sizeof(int32_t));
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_sortperm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static std::atomic<unsigned long long> seen{0};
+    ensure_dyn_lds((const void*)k_sortperm, 160 * 1024, seen);
     hipLaunchKernelGGL(k_sortperm, dim3(B), dim3(n >= 2048 ? 1024 : 256), bytes, s, cost, order, K, n, active);
 }
 
@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
 }
 void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s) {
     const size_t bytes = (size_t)K * (8 + 4 + 4 + 4);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_alias_build, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    static std::atomic<unsigned long long> seen{0};
+    ensure_dyn_lds((const void*)k_alias_build, 160 * 1024, seen);
     hipLaunchKernelGGL(k_alias_build, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active);
 }
 

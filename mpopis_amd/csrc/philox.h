@@ -21,7 +21,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // log(u) for a normal-range u in (0, 1): the classic argument reduction u = 2^k m, m in [sqrt(1/2), sqrt(2)), s = f/(2+f),
 // f = m - 1, and the degree-14 odd minimax polynomial in s of Sun's fdlibm (e_log.c; error < 1 ulp).  No special cases
-// (the Box-Muller uniforms are (i + 0.5) 2^-53), no double-double arithmetic: ~35 VALU ops.
+// (the Box-Muller uniforms are (i + 0.5) 2^-53, clamped below 1), no double-double arithmetic: ~35 VALU ops.
 __device__ __forceinline__ double log_unit(double u) {
     int k = __builtin_amdgcn_frexp_exp(u);                     // u = m 2^k, m in [0.5, 1)
     double m = __builtin_amdgcn_frexp_mant(u);
@@ -71,7 +71,8 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
     // u = ((a >> 11) + 0.5) 2^-53 for the 64-bit word a = (hi:lo), one rounding: (a >> 11) = hi 2^21 + (lo >> 11), so
     // u = hi 2^-32 + ((lo >> 11) + 0.5) 2^-53 with both conversions exact -- two v_cvt_f64_u32 and two fmas per uniform
-    const double u1 = fma((double)r[1], 0x1p-32, fma((double)(r[0] >> 11), 0x1p-53, 0x1p-54));
+    // (the largest word, a >> 11 = 2^53 - 1, would round to u1 = 1.0 -> log = 0 -> rsq(0) = inf -> NaN normals: keep u1 < 1)
+    const double u1 = fmin(fma((double)r[1], 0x1p-32, fma((double)(r[0] >> 11), 0x1p-53, 0x1p-54)), 1.0 - 0x1p-53);
     const double u2 = fma((double)r[3], 0x1p-32, fma((double)(r[2] >> 11), 0x1p-53, 0x1p-54));
     // sqrt of a positive normal-range number: v_rsq_f64 seed + coupled Newton step + residual correction (1 ulp, see
     // tools/rcp_acc.hip) instead of the library sqrt with its denormal rescaling (8 instead of 18 VALU ops)

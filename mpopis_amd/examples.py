@@ -1,7 +1,8 @@
 """simulate_car_racing / simulate_mountaincar (src/examples/car_example.jl:51-416,
-mountaincar_example.jl:49-207): the trial loop runs as ONE device-resident batch (all trials are
-independent, car_example.jl:170), optionally sharded over ranks with one RCCL gather of the per-trial
-summary records (torch.distributed, backend nccl == RCCL).  Prints the reference's tables."""
+mountaincar_example.jl:49-207): the trial loop runs as ONE device-resident batch per rank (all trials are
+independent, car_example.jl:170), optionally sharded over ranks (trial k -> rank (k-1) mod G) with one RCCL
+gather of the per-trial summary records (mpopis_gather_summary behind the C ABI when the process group is
+nccl == RCCL; torch.distributed's own gather for the gloo CPU tests).  Prints the reference's tables."""
 import math
 import time
 import numpy as np
@@ -76,36 +77,42 @@ def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="ce
         seed = int(np.random.default_rng().integers(1, 10 ** 10))
     U0 = np.zeros(num_cars * 2) if U0 is None else np.asarray(U0, dtype=np.float64)
     cov_mat = np.tile([0.0625, 0.1], num_cars) if cov_mat is None else cov_mat
+    if world > 1:
+        sd = [seed]                                    # the seed must be common to all ranks
+        dist.broadcast_object_list(sd, src=0)
+        seed = sd[0]
     mine = shard_trials(num_trials, rank, world)
-    rec = np.zeros((0, RECORD_LEN + 2))
     t0 = time.time()
+    # every rank keeps a handle (even with no trials: it takes part in the collective); all of a rank's trials
+    # k0, k0+G, ... live in ONE resident batch, slot i seeded like the reference's trial k_i: seed!(pol, seed + k) (:187-188)
+    eng = Engine("car", num_cars, pt, num_samples, horizon, batch=max(len(mine), 1), lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
+                 elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
+                 cma_sigma=cma_σ, seed=seed, device=device, cov=cov_mat, U0=U0)
+    r = np.zeros((0, RECORD_LEN))
     if mine:
-        # slots of one handle use consecutive seeds seed+b+1: give every trial id its own handle seed offset
-        groups = []                      # consecutive runs of trial ids with stride `world`
+        eng.seed_slots([seed + k for k in mine])
+        eng.set_state_noise(state_x_sigma, state_y_sigma, state_ψ_sigma)
+        r = eng.run_trials(num_steps, laps)
+    ex_time = time.time() - t0                 # Ex Time of this rank's batch (its trials run concurrently)
+    n_max = (num_trials + world - 1) // world
+    if world > 1 and dist.get_backend() == "nccl":
+        # RCCL gather behind the C ABI (mpopis_gather_summary); slot 15 of a record (status) carries the rank's Ex Time
+        r = r.copy()
+        r[:, 15] = ex_time
+        eng.comm_init_from_dist(dist)
+        parts = eng.gather_summary(r, n_max)
+        eng.close()
+        if parts is None:
+            return None, None
         rows = []
-        for k in mine:
-            groups.append(k)
-        # trial ids on this rank are k0, k0+world, ...: run them as separate 1-slot seeds inside one batch when world==1
-        if world == 1:
-            eng = Engine("car", num_cars, pt, num_samples, horizon, batch=len(mine), lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
-                         elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
-                         cma_sigma=cma_σ, seed=seed, device=device, cov=cov_mat, U0=U0)
-            eng.set_state_noise(state_x_sigma, state_y_sigma, state_ψ_sigma)
-            r = eng.run_trials(num_steps, laps)
-            eng.close()
-            rows = [np.concatenate([[k], r[i], [0.0]]) for i, k in enumerate(mine)]
-        else:
-            for k in mine:
-                eng = Engine("car", num_cars, pt, num_samples, horizon, batch=1, lam=λ, alpha=α, ais_its=ais_its, lam_ais=λ_ais,
-                             elite_threshold=(cma_elite_threshold if pt == "cmamppi" else ce_elite_threshold), sigma_est=str(ce_Σ_est).lstrip(":"),
-                             cma_sigma=cma_σ, seed=seed + k - 1, device=device, cov=cov_mat, U0=U0)
-                eng.set_state_noise(state_x_sigma, state_y_sigma, state_ψ_sigma)
-                r = eng.run_trials(num_steps, laps)
-                eng.close()
-                rows.append(np.concatenate([[k], r[0], [0.0]]))
-        rec = np.array(rows)
-        rec[:, -1] = time.time() - t0          # Ex Time of this rank's batch (trials run concurrently)
-    allrec = _gather_records(rec, dist)
+        for g, part in enumerate(parts):
+            for i, row in enumerate(part):
+                rows.append(np.concatenate([[1 + g + i * world], row[:15], [0.0], [row[15]]]))
+        allrec = np.array(rows)
+    else:
+        eng.close()
+        rec = np.array([np.concatenate([[k], r[i], [ex_time]]) for i, k in enumerate(mine)]).reshape(-1, RECORD_LEN + 2)
+        allrec = _gather_records(rec, dist)
     if allrec is None:
         return None, None
     allrec = allrec[np.argsort(allrec[:, 0])]

@@ -464,6 +464,7 @@ void orc_philox_normals(uint64_t seed, uint32_t slo, uint32_t shi, int64_t n, do
         philox_pair(seed, slo, shi, (uint64_t)j, &a, &b);
         double u1 = ((double)(a >> 11) + 0.5) * two_m53;
         double u2 = ((double)(b >> 11) + 0.5) * two_m53;
+        if (u1 >= 1.0) u1 = 1.0 - two_m53;          /* a >> 11 = 2^53 - 1 rounds to 1.0: keep log(u1) < 0 (same clamp as the device generator) */
         double R = sqrt(-2.0 * log(u1));
         double th = 6.283185307179586476925286766559 * u2;
         out[2 * j] = R * cos(th);

@@ -116,3 +116,50 @@ def test_cartpole_env_and_simulate(M, oracle):
     assert np.array_equal(rec[:, :15], rec2[:, :15])
     with pytest.raises(TypeError):
         M.simulate_cartpole(num_trails=1)
+
+
+def test_sharded_trials_in_one_handle_match_full_run(M):
+    """SURVEY 8e partitioning: a rank holding trials {1,3,5,7} (rank 0 of 2) keeps them in ONE handle via
+    mpopis_seed_slots and must reproduce exactly the same trials of the unsharded num_trials=8 run
+    (trial k draws from seed + k, car_example.jl:187-188)."""
+    from mpopis_amd.engine import Engine
+    from mpopis_amd.examples import shard_trials
+    kw = dict(lam=10.0, ais_its=3, lam_ais=20.0, cov=[0.0625, 0.1])
+    seed = 777
+    full = Engine("car", 1, "musigmaaismppi", 256, 20, batch=8, seed=seed, **kw)
+    rec_full, act_full = full.run_trials(15, 2, log_actions=True)
+    full.close()
+    for rank in (0, 1):
+        mine = shard_trials(8, rank, 2)
+        assert mine == ([1, 3, 5, 7] if rank == 0 else [2, 4, 6, 8])
+        part = Engine("car", 1, "musigmaaismppi", 256, 20, batch=len(mine), seed=seed, **kw)
+        part.seed_slots([seed + k for k in mine])
+        rec, act = part.run_trials(15, 2, log_actions=True)
+        part.close()
+        idx = [k - 1 for k in mine]
+        assert np.array_equal(act, act_full[idx])                      # bit-identical actions ...
+        assert np.array_equal(rec[:, :15], rec_full[idx][:, :15])      # ... and records
+    # different seeds really give different trials
+    assert not np.array_equal(act_full[0], act_full[1])
+
+
+def test_gather_summary_through_the_abi(M):
+    """mpopis_gather_summary: world == 1 copy path, and a real one-rank RCCL communicator (dlopen of librccl,
+    ncclGetUniqueId, ncclCommInitRank, ncclGather/ncclAllGather on the handle's stream)."""
+    from mpopis_amd.engine import Engine
+    from mpopis_amd._lib import RECORD_LEN
+    eng = Engine("car", 1, "gmppi", 64, 5, batch=3, lam=10.0, cov=[0.0625, 0.1])
+    rec = np.arange(3 * RECORD_LEN, dtype=np.float64).reshape(3, RECORD_LEN)
+    eng.comm_init(0, 1)
+    parts = eng.gather_summary(rec, 5)                                  # n_max > n_local: padded rows are dropped again
+    assert len(parts) == 1 and np.array_equal(parts[0], rec)
+    eng.close()
+    eng = Engine("car", 1, "gmppi", 64, 5, batch=3, lam=10.0, cov=[0.0625, 0.1])
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(0, 1, uid)
+    parts = eng.gather_summary(rec, 3)
+    assert len(parts) == 1 and np.array_equal(parts[0], rec)
+    parts = eng.gather_summary(rec[:0], 3)                              # a rank without trials
+    assert parts[0].shape == (0, RECORD_LEN)
+    eng.close()
