@@ -198,6 +198,12 @@ int  mpopis_gather_summary(mpopis_handle *h, const double *records, int32_t n_lo
                            double *out, int32_t *counts);
 int  mpopis_comm_destroy(mpopis_handle *h);
 
+/* Execution knob (default: 2 parts): a handle with >= 2 slots splits its batch into parts that run as independent chains on
+ * their own HIP streams, so that the latency-bound links of one chain (Cholesky, weights) hide under another's rollouts.
+ * on = 0: one stream (time kernels in isolation); 1 or 2: two halves; 3, 4: that many parts.  Results do not depend on it
+ * (bit-identical per slot). */
+int  mpopis_set_overlap(mpopis_handle *h, int32_t on);
+
 /* ---- measurement hooks (bench.py; HIP events on the engine's own stream) ----------------------- */
 int  mpopis_timing_enable(mpopis_handle *h, int32_t on);   /* 0 off; 1 every kernel class; else a mask: bit (i + 1) = class i of
                                                               * mpopis_timing_read's name list (2 = "rollout" only: 2 events per launch) */

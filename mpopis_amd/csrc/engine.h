@@ -34,6 +34,12 @@ inline void ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long 
     seen.fetch_or(bit, std::memory_order_relaxed);
 }
 
+// Wave issue priority (s_setprio 0..3, default 0): every kernel of the per-slot chain EXCEPT the rollout raises it.  When the
+// two half-batch chains share the chip (engine_api.hip, policy_step_enqueue), the short latency-bound links of one chain then
+// win the SIMD issue arbitration against the other half's long-running rollout waves instead of being starved by them
+// (measured: k_weights 9 us alone, 155 us next to a rollout kernel at equal priority).
+#define MPOPIS_HI_PRIO() __builtin_amdgcn_s_setprio(3)
+
 constexpr int kMaxCars = 4;
 constexpr int kMaxAs = 2 * kMaxCars;
 
@@ -92,7 +98,7 @@ void launch_finalize_env(const double* wn, double* U, double* control, int B, in
                          const EnvDesc& env, hipStream_t s);
 
 // layout converters between the ABI's cs x K column-major and the engine's [cs][K]
-void launch_transpose_in(const double* src_colmajor, double* dst_rows, int B, int cs, int K, hipStream_t s);
+void launch_transpose_in(const double* src_colmajor, double* dst_rows, int B, int cs, int K, hipStream_t s, size_t src_stride = 0 /* 0: cs*K */);
 void launch_transpose_out(const double* src_rows, const double* shiftA, const double* shiftB,
                           double* dst_colmajor, int B, int cs, int K, hipStream_t s);
 

@@ -12,6 +12,7 @@ using namespace mpopis;
 namespace mpopis {
 
 __global__ void __launch_bounds__(256) k_scale_rows(double* Z, const double* dsc, int cs, int K) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.z, r = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if (k < K) Z[((size_t)b * cs + r) * K + k] *= dsc[(size_t)b * cs + r];
 }
@@ -19,7 +20,8 @@ void launch_scale_rows(double* Z, const double* dsc, int B, int cs, int K, hipSt
     hipLaunchKernelGGL(k_scale_rows, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, dsc, cs, K);
 }
 
-__global__ void __launch_bounds__(256) k_add_active(const double* x, double* y, int n, const int* active) {   // y[b] += x[b]
+__global__ void __launch_bounds__(256) k_add_active(const double* x, double* y, int n, const int* active) {
+    MPOPIS_HI_PRIO();   // y[b] += x[b]
     const int b = blockIdx.y; if (active && !active[b]) return;
     const int i = blockIdx.x * 256 + threadIdx.x; if (i >= n) return;
     y[(size_t)b * n + i] = y[(size_t)b * n + i] + x[(size_t)b * n + i];

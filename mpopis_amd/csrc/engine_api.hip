@@ -8,6 +8,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 
@@ -114,6 +115,13 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     h->cfg = *cfg;
     HIPCHK((mpopis_handle*)nullptr, hipSetDevice(cfg->device));
     HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < mpopis_handle::kMaxSplit - 1; ++i) {
+        HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
+        HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_skew[i], hipEventDisableTiming));
+    }
+    if (const char* e = getenv("MPOPIS_NSPLIT")) h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e)));   // experiments (tools/ab)
     h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
     h->as = car ? 2 * cfg->num_cars : 1;
     h->ss = car ? 8 * cfg->num_cars : (cfg->env_kind == MPOPIS_ENV_CARTPOLE ? 4 : 2);
@@ -180,10 +188,15 @@ void mpopis_destroy(mpopis_handle* h) {
     if (h->comm) (void)mpopis_comm_destroy(h);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto st : h->xstream) if (st) (void)hipStreamSynchronize(st);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto st : h->xstream) if (st) (void)hipStreamDestroy(st);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (auto e : h->ev_join) if (e) (void)hipEventDestroy(e);
+    for (auto e : h->ev_skew) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -476,6 +489,12 @@ int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double*
     return h->run_trials(num_steps, laps, records, actions);
 }
 
+int mpopis_set_overlap(mpopis_handle* h, int32_t on) {
+    if (!h) return MPOPIS_ERR_ARG;
+    h->nsplit = on ? std::max(2, std::min((int)mpopis_handle::kMaxSplit, (int)on)) : 1;      // 1: two halves; 2..4: that many parts
+    return MPOPIS_OK;
+}
+
 int mpopis_timing_enable(mpopis_handle* h, int32_t on) {
     if (!h) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
@@ -552,8 +571,57 @@ void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const doubl
 
 // calculate_trajectory_costs(pol, env) for the configured policy + functor tail.  `injected`: noise
 // staged in d_Zin / d_resi_in / d_resu_in, else device Philox streams (mpc_step, iteration).
+// Slot views: every per-slot buffer is laid out [B][...], so "slots [b0, b0 + nb)" is the same handle with its pointers moved.
+void mpopis_handle::shift_slots(ptrdiff_t db) {
+    const ptrdiff_t nn = (ptrdiff_t)cs * cs, per = (ptrdiff_t)cs * K;
+    auto mv = [db](auto*& p, ptrdiff_t stride) { if (p) p += db * stride; };
+    mv(d_x, ss); mv(d_xext, kMaxCars * kCarExt); mv(d_t, 1); mv(d_done, 1);
+    mv(d_U, cs); mv(d_Ucur, cs); mv(d_Uin, cs);
+    mv(d_Sig, nn); mv(d_L, nn); mv(d_tmpS, nn); mv(d_dscale, cs);
+    mv(d_Z, per); mv(d_E, per); mv(d_Zin, (ptrdiff_t)N * per); mv(d_cost, K); mv(d_w, K); mv(d_wsum, 1);
+    mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
+    mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_seeds, 1);
+    mv(d_order, K); mv(d_resi, K); mv(d_alias, K); mv(d_residx_log, (ptrdiff_t)std::max(1, N - 1) * K); mv(d_resi_in, (ptrdiff_t)(N - 1) * K);
+    mv(d_resu, K); mv(d_accept, K); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
+    mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
+    mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
+    mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_fro, 1); mv(d_lan_m, 1);
+    mv(alive_gate, 1);
+}
+
+// pol(env) for all slots.  With >= 2 slots the batch is split into nsplit (default 2) parts that run as independent chains on
+// their own streams, each started one sampler later than the previous: while one part sits in a latency-bound link of its chain
+// (Cholesky: nb workgroups on 256 CUs; weights; the scatter's finish), the other half's rollout / sampler fills the chip.
+// Per-slot results are bit-identical to the single-stream order (every kernel is slot-independent and deterministic).
 int mpopis_handle::policy_step_enqueue(bool injected) {
+    const int B0 = B, np = std::min(nsplit, B0);
+    if (np < 2) {
+        const int rc = step_enqueue_view(injected, nullptr, nullptr);
+        mpc_step += 1;
+        return rc;
+    }
+    (void)hipEventRecord(ev_fork, stream);                      // the other streams start after everything already queued on the main stream
+    hipStream_t main_stream = stream;
+    int rc = 0, b0 = 0;
+    for (int p = 0; p < np; ++p) {
+        const int nbp = B0 / np + (p < B0 % np ? 1 : 0);
+        if (p > 0) { stream = xstream[p - 1]; (void)hipStreamWaitEvent(stream, ev_fork, 0); }
+        B = nbp;
+        // part p starts when part p-1 has entered its first rollout (one sampler later) and tells part p+1 when it gets there itself
+        const int r = step_enqueue_view(injected, p > 0 ? ev_skew[p - 1] : nullptr, p + 1 < np ? ev_skew[p] : nullptr);
+        if (!rc) rc = r;
+        if (p > 0) (void)hipEventRecord(ev_join[p - 1], stream);
+        shift_slots(nbp); b0 += nbp;
+    }
+    shift_slots(-b0); B = B0; stream = main_stream;
+    for (int p = 1; p < np; ++p) (void)hipStreamWaitEvent(stream, ev_join[p - 1], 0);   // later work on the main stream sees every part
+    mpc_step += 1;
+    return rc;
+}
+
+int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEvent_t record_after_first_sampler) {
     const int pol = cfg.policy;
+    if (wait_first) (void)hipStreamWaitEvent(stream, wait_first, 0);
     const size_t nn = (size_t)cs * cs, per = (size_t)cs * K;
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
     if (!status_sticky) fill_i32(d_status, 0, B, stream);
@@ -587,11 +655,9 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
         double* Zdst = dsc ? d_E : d_Z;
         bool fused = false;
         if (injected) {
-            // B x N x (cs x K col-major) -> rows; slot stride N*per
-            for (int b = 0; b < B; ++b) {
-                if (pol == MPOPIS_POL_MPPI) launch_mppi_Z_in(d_Zin + ((size_t)b * N + (n - 1)) * per, Zdst + (size_t)b * per, 1, T, K, as, stream);
-                else launch_transpose_in(d_Zin + ((size_t)b * N + (n - 1)) * per, Zdst + (size_t)b * per, 1, cs, K, stream);
-            }
+            // B x N x (cs x K col-major) -> rows; source slot stride N*per
+            if (pol == MPOPIS_POL_MPPI) launch_mppi_Z_in(d_Zin, Zdst, B, T, K, as, stream);       // N == 1
+            else launch_transpose_in(d_Zin + (size_t)(n - 1) * per, Zdst, B, cs, K, stream, (size_t)N * per);
             if (dsc) launch_scale_rows(Zdst, dsc, B, cs, K, stream);
         } else if (!dsc && pol != MPOPIS_POL_MPPI) {
             // dense proposal: draw inside the unwhitening kernel when the shape allows it (no Z round trip through HBM)
@@ -602,6 +668,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
         }
         if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
         time_end();
+        if (n == 1 && record_after_first_sampler) (void)hipEventRecord(record_after_first_sampler, stream);   // the next part starts when this one enters its first rollout
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active, d_iters, n);   // also records iters_run = n for the active slots
         // ---- adapt (μ, Σ′) ----------------------------------------------------------------------
@@ -616,6 +683,5 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     launch_wmean(d_E, d_w, d_Ucur, d_Uin, d_wn, B, cs, K, 0, alive_gate, stream);
     launch_finalize_env(d_wn, d_U, d_control, B, cs, as, T, env, stream);
     time_end();
-    mpc_step += 1;
     return MPOPIS_OK;
 }

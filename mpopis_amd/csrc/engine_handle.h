@@ -7,6 +7,12 @@ struct mpopis_handle {
     int B = 0, K = 0, T = 0, as = 0, ss = 0, cs = 0, N = 1;
     double gamma = 0.0;
     hipStream_t stream = nullptr;
+    // Two half-batches on two streams (engine_api.hip, policy_step_enqueue): the latency-bound links of one half's chain
+    // (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) run under the other half's throughput-bound kernels
+    static constexpr int kMaxSplit = 4;
+    hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {nullptr, nullptr, nullptr}, ev_skew[kMaxSplit - 1] = {nullptr, nullptr, nullptr};
+    int nsplit = 2;                                                            // parts the batch is split into (1 = single stream)
     mpopis::EnvDesc env{};
     std::string err;
     std::vector<void*> allocs;
@@ -54,6 +60,8 @@ struct mpopis_handle {
     void prepare_state();
     void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters = nullptr, int iter_n = 0);
     int policy_step_enqueue(bool injected);
+    int step_enqueue_view(bool injected, hipEvent_t wait_first, hipEvent_t record_after_first_sampler);
+    void shift_slots(ptrdiff_t db);                           // move every per-slot device pointer by db slots (slot views)
     int ais_update(int n, bool injected);
     int run_trials(int num_steps, int laps, double* records, double* actions);
     void init_cma_constants();

@@ -24,6 +24,7 @@ constexpr int kCmaThreads = 1024, kCmaWaves = kCmaThreads / 64;
 __global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restrict__ Cdw, const double* __restrict__ froC, const double* __restrict__ E, const int32_t* __restrict__ order,
                                                    const double* __restrict__ ws, double* Ucur, double* scal, double* vec, double* sig2,
                                                    int cs, int K, int n_iter, CmaConsts cc, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[kCmaWaves];
@@ -78,6 +79,7 @@ __global__ void __launch_bounds__(kCmaThreads) k_cma_paths(const double* __restr
 
 // Σ = (1-c1-cμ)Σ + c1 (pΣ pΣ' + (1-hσ) cΣ (2-cΣ) Σ) .+ cμ temp_sum ; Σ = triu(Σ) + triu(Σ,1)'   (:598-599)
 __global__ void __launch_bounds__(256) k_cma_sigma_update(double* Sig, const double* scal, const double* vec, int cs, CmaConsts cc, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;

@@ -40,6 +40,7 @@ __device__ __forceinline__ double ld_L(const double* __restrict__ L, int n, int 
 // part[b][J] = sum of squares of the entries of block column J of L^-1 (rows/cols < n)
 __global__ void __launch_bounds__(kInvThreads) k_trtri_fro(const double* __restrict__ Lall, size_t Lstride, int n, int nb, double* __restrict__ part,
                                                            const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y, J = blockIdx.x;
     if (active && !active[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh_inv[];
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                                                                  const double* __restrict__ part, int nb, const double* __restrict__ scale,
                                                                  double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
                                                                  int* __restrict__ msteps, int n, int* status, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh_lan[];

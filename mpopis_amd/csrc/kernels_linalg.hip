@@ -34,6 +34,7 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {     // src is 
 template <bool LDS, int NTHR>
 __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
                                                int n, int npad, const double* scale, int* status, int* active) {
+    MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int failed;
     __shared__ double rdiag[kNB];
@@ -224,6 +225,7 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
 // Slow path: only taken when α != 1 (γ != 0); no BASELINE config uses it.
 __global__ void __launch_bounds__(256) k_chol_solve_gvec(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Uorig,
                                                          double gamma, double* __restrict__ g, int n, const int* active) {
+    MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double y[];
     const int b = blockIdx.x;
     if (active && !active[b]) return;
@@ -266,6 +268,7 @@ void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma,
 // mean over gathered columns: mu[r] = (1/m) Σ_j X[r][idx[j]] ; optionally weighted by cw[j] (CMA δw, no division)
 __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ X, const int32_t* __restrict__ idx, const double* __restrict__ cw,
                                                      double* __restrict__ mu, size_t mu_stride, int cs, int K, int m, int divide, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y, r = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[4];

@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
                                                           const double* __restrict__ mu_corr, double wtot_unweighted,
                                                           double* __restrict__ mu_aug, double* __restrict__ u_add, const double* __restrict__ wsum) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
@@ -300,6 +301,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
 
 // rs[b][a] = 1/sqrt(S[b][a][a])
 __global__ void __launch_bounds__(256) k_inv_sd(const double* __restrict__ Sg, double* __restrict__ rs, int cs, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y, a = blockIdx.x * 256 + threadIdx.x;
     if ((active && !active[b]) || a >= cs) return;
     rs[(size_t)b * cs + a] = 1.0 / sqrt(Sg[(size_t)b * cs * cs + (size_t)a * (cs + 1)]);
@@ -311,6 +313,7 @@ __global__ void __launch_bounds__(256) k_inv_sd(const double* __restrict__ Sg, d
 // standardized = 0 gives the :lw variant (same intensity on the unstandardised scatter: rs == 1, Q = Σ_k xc_a² xc_b²).
 __global__ void __launch_bounds__(256) k_ss_shrink(double* __restrict__ Sg, const double* __restrict__ Q, const double* __restrict__ rs,
                                                    int cs, int m, double ridge, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[8];
@@ -345,6 +348,7 @@ __global__ void __launch_bounds__(256) k_ss_shrink(double* __restrict__ Sg, cons
 }
 // LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas): closed forms in tr(S), tr(S²) (Chen et al. 2010), F = tr(S)/p I
 __global__ void __launch_bounds__(256) k_common_shrink(double* __restrict__ Sg, int cs, int m, int oas, double ridge, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[8];

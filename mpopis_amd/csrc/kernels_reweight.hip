@@ -35,6 +35,7 @@ __device__ __forceinline__ double block_reduce(double v, double* sh) {
 
 __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cost, double* __restrict__ w, int K,
                                                   double neg_inv_lambda, const int* active, int* status, double* __restrict__ wsum) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[16];
@@ -66,6 +67,7 @@ void launch_weights(const double* cost, double* w, int B, int K, double lambda, 
 __global__ void __launch_bounds__(256) k_wmean(const double* __restrict__ E, const double* __restrict__ w,
                                                const double* shiftA, const double* shiftB, double* __restrict__ out,
                                                int cs, int K, int normalize, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y, r = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double sh[4];
@@ -98,6 +100,7 @@ void launch_wmean(const double* E, const double* w, const double* shiftA, const 
 // `as` entries of U never change)
 __global__ void __launch_bounds__(256) k_finalize(const double* __restrict__ wn, double* U, double* control,
                                                   int cs, int as, int T, EnvDesc env) {
+    MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double wc[];
     const int b = blockIdx.x;
     double* Ub = U + (size_t)b * cs;
@@ -114,10 +117,10 @@ void launch_finalize_env(const double* wn, double* U, double* control, int B, in
 }
 
 // cs x K column-major (ABI / Julia)  <->  [cs][K] rows (engine)
-__global__ void __launch_bounds__(256) k_transpose_in(const double* __restrict__ src, double* __restrict__ dst, int cs, int K) {
+__global__ void __launch_bounds__(256) k_transpose_in(const double* __restrict__ src, size_t src_stride, double* __restrict__ dst, int cs, int K) {
     __shared__ double tile[32][33];
     const int b = blockIdx.z;
-    const double* s = src + (size_t)b * cs * K;
+    const double* s = src + (size_t)b * src_stride;
     double* d = dst + (size_t)b * cs * K;
     const int r0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                    // 32 x 8
@@ -140,8 +143,8 @@ __global__ void __launch_bounds__(256) k_transpose_out(const double* __restrict_
     __syncthreads();
     for (int j = ty; j < 32; j += 8) { const int k = k0 + j, r = r0 + tx; if (k < K && r < cs) d[(size_t)k * cs + r] = tile[tx][j]; }
 }
-void launch_transpose_in(const double* src, double* dst, int B, int cs, int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_transpose_in, dim3((cs + 31) / 32, (K + 31) / 32, B), dim3(256), 0, s, src, dst, cs, K);
+void launch_transpose_in(const double* src, double* dst, int B, int cs, int K, hipStream_t s, size_t src_stride) {
+    hipLaunchKernelGGL(k_transpose_in, dim3((cs + 31) / 32, (K + 31) / 32, B), dim3(256), 0, s, src, src_stride ? src_stride : (size_t)cs * K, dst, cs, K);
 }
 void launch_transpose_out(const double* src, const double* shiftA, const double* shiftB, double* dst, int B, int cs, int K, hipStream_t s) {
     hipLaunchKernelGGL(k_transpose_out, dim3((cs + 31) / 32, (K + 31) / 32, B), dim3(256), 0, s, src, shiftA, shiftB, dst, cs, K);

@@ -21,7 +21,7 @@ namespace mpopis {
 // NC cars x SPB sample-waves per workgroup: the SPB*64 samples of a workgroup share one LDS copy of the track tables
 // LOG: the trajectory logger is on (a.traj != nullptr) -- only then is the heading angle psi itself tracked
 template <int NC, int SPB, bool LOG>
-__global__ void __launch_bounds__(64 * NC * SPB) k_rollout_car(RolloutArgs a) {
+__global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;

@@ -64,6 +64,7 @@ void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_orde
 // resampling draws for :pmcmppi (rand(rng, Categorical(ws), K), :805): i uniform in [0,K), u in [0,1)
 __global__ void __launch_bounds__(256) k_sample_resample_draws(int32_t* di, double* du, int K, const uint64_t* seeds,
                                                                uint32_t slo, uint32_t shi, const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     const int k = blockIdx.x * 256 + threadIdx.x;

@@ -11,6 +11,7 @@ namespace mpopis {
 // sortperm.  n = next pow2 >= K, padded with (+inf, big index).
 __global__ void __launch_bounds__(1024) k_sortperm(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int n,
                                                    const int* active) {
+    MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* key = reinterpret_cast<double*>(smem);
     int32_t* idx = reinterpret_cast<int32_t*>(smem + (size_t)n * sizeof(double));
@@ -48,6 +49,7 @@ void launch_sortperm(const double* cost, int32_t* order, int B, int K, const int
 // leaves the AIS loop (active[b] = 0) -- nothing of this iteration's update is applied.
 __global__ void __launch_bounds__(256) k_elite_break(const double* __restrict__ cost, const int32_t* __restrict__ order, int K, int m_elite,
                                                      int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (!active[b]) return;
     __shared__ double sh[4];
@@ -73,6 +75,7 @@ void launch_elite_break(const double* cost, const int32_t* order, int B, int K, 
 // pairing loop keeping the current large in registers (LIFO => it is re-popped immediately).
 __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
                                                     int K, const int* active) {
+    MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* a = reinterpret_cast<double*>(smem);
     int32_t* al = reinterpret_cast<int32_t*>(smem + (size_t)K * 8);
@@ -120,6 +123,7 @@ __global__ void __launch_bounds__(256) k_alias_sample(const double* __restrict__
                                                       const int32_t* __restrict__ di, size_t di_stride, const double* __restrict__ du,
                                                       int32_t* __restrict__ out, int32_t* __restrict__ log, size_t log_stride, int K,
                                                       const int* active) {
+    MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     const int k = blockIdx.x * 256 + threadIdx.x;

@@ -212,3 +212,24 @@ def test_cmamppi_dense_ill_conditioned_sigma(eng_mod, oracle, track, cs_T, cond)
         assert np.max(np.abs(got["control"][b] - ref["control"])) < 1e-7 * max(1.0, cond * 1e-4)
         assert sig_err(Sd[b], ref["Sigma_last"]) < 1e-8 * max(1.0, cond * 1e-4)
     eng.close()
+
+
+@pytest.mark.parametrize("kind,ncars,K,N", [("musigmaaismppi", 1, 4096, 10), ("cmamppi", 2, 1024, 4), ("pmcmppi", 1, 1024, 4), ("cemppi", 1, 150, 10)])
+def test_two_stream_overlap_is_bit_identical(eng_mod, track, kind, ncars, K, N):
+    """The two-half-batch / two-stream schedule (default) must give exactly the single-stream results, slot by slot
+    (B = 5: parts of 3 + 2 slots, and 2 + 1 + 1 + 1 with four streams), including through the closed-loop harness."""
+    outs = []
+    for overlap in (2, 0, 4):
+        eng = eng_mod.Engine("car", ncars, kind, K, 50, batch=5, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, sigma_est="ss",
+                             cma_sigma=0.75, cov=np.tile([0.0625, 0.1], ncars), track=track, seed=4242)
+        eng.set_overlap(overlap)
+        res = []
+        for _ in range(2):
+            got = eng.policy_step(None, want_E=True)
+            res += [got["control"], got["cost"], got["weights"], got["E"], got["iters_run"], eng.get_U(), eng.get_Sigma()]
+        rec, act = eng.run_trials(6, 2, log_actions=True)
+        res += [rec[:, :15], act]
+        eng.close()
+        outs.append(res)
+    for a, b, c in zip(*outs):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
