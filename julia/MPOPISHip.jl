@@ -1,7 +1,7 @@
 # MPOPISHip.jl -- the reference-side binding for libmpopis_hip.so (include/mpopis.h).
 #
-# SOURCE ONLY: Julia is not installed in the build image, so this file has never been executed
-# there; it is the thin `ccall` layer a MPOPIS maintainer adds.  It plugs in exactly where the
+# EXPERIMENTAL, SOURCE ONLY: Julia is not installed in the build image, so this file has never been executed
+# there (expect to fix typos on first load); it is the thin `ccall` layer a MPOPIS maintainer adds.  It plugs in exactly where the
 # reference already dispatches on the env type for its EnvPool backend
 # (src/mppi_mpopi_policies.jl:148 vs :186, :240 vs :261): more specific methods of
 #     (pol::AbstractPathIntegralPolicy)(env)         -> mpopis_policy_step
@@ -45,6 +45,11 @@ elite(pol::CMAMPPI_Policy) = 1.0 - pol.m_elite / pol.params.num_samples
 elite(pol) = 0.8
 cma_sigma(pol::CMAMPPI_Policy) = pol.σ
 cma_sigma(pol) = 1.0
+# MPOPIS_SIGMA_EST_*: CEMPPI_Policy stores the estimator object, not the symbol (src/mppi_mpopi_policies.jl:386,414-426)
+sigma_est(pol::CEMPPI_Policy) = sigma_est(pol.Σ_estimation_method)
+sigma_est(::MPOPIS.SimpleCovariance) = 0                                                  # :mle
+sigma_est(m::MPOPIS.LinearShrinkage) = Dict(:ss => 1, :lw => 2, :rblw => 3, :oas => 4)[m.shrinkage]
+sigma_est(pol) = 0
 
 car_param_vector(env::CarRacingEnv) = Float64[getfield(env.params, f) for f in fieldnames(typeof(env.params))] |>
                                       v -> vcat(v, env.dt, env.δt)
@@ -60,7 +65,7 @@ function handle(pol, env)
     get!(HANDLES, pol) do
         kind, ncars = env_kind(env)
         cfg = Config(0, kind, ncars, policy_id(pol), pol.params.num_samples, pol.params.horizon, 1, ais_its(pol),
-                     0, pol.params.log, pol.params.λ, pol.params.α, lam_ais(pol), elite(pol), cma_sigma(pol), rand(UInt64))
+                     sigma_est(pol), pol.params.log, pol.params.λ, pol.params.α, lam_ais(pol), elite(pol), cma_sigma(pol), rand(UInt64))
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:mpopis_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out)
         rc == 0 || error(unsafe_string(ccall((:mpopis_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -105,6 +110,14 @@ function hip_policy_call(pol::AbstractPathIntegralPolicy, env)
     end
     if pol.params.log
         pol.logger.traj_costs = cost; pol.logger.traj_weights = w
+        # pol.logger.trajectories[k][t, :] = env.state (src/utils.jl:139-141): K matrices of T x ss, which is exactly the
+        # per-sample block layout mpopis_get_trajectories returns (column-major T x ss per sample)
+        T, ss = pol.params.horizon, pol.params.ss
+        buf = Vector{Float64}(undef, K * T * ss)
+        GC.@preserve buf check(h, ccall((:mpopis_get_trajectories, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, buf))
+        for k in 1:K
+            copyto!(pol.logger.trajectories[k], 1, buf, (k - 1) * T * ss + 1, T * ss)
+        end
     end
     return as == 1 ? control : reshape(control, as, 1)        # get_model_controls returns as×1 (utils.jl:55-67)
 end

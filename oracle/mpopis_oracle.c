@@ -146,7 +146,8 @@ double orc_car_reward(const double *p, int P, const double *tx, const double *ty
 }
 
 /* ======================================================================================
- * MountainCar [3P: ReinforcementLearningEnvironments MountainCarEnv, continuous=true],
+ * MountainCar [3P: ReinforcementLearning.jl 0.11 -> ReinforcementLearningEnvironments,
+ * src/environments/examples/MountainCarEnv.jl: MountainCarEnvParams(continuous = true), _step!(env, force)],
  * functor + reward override: src/examples/mountaincar_example.jl:4-22
  * ====================================================================================== */
 void orc_mountaincar_default_params(double *p) {
@@ -177,8 +178,8 @@ static double mc_reward(const double *p, const double *s, int done) {
 }
 
 /* ======================================================================================
- * CartPole [3P: ReinforcementLearningEnvironments CartPoleEnv, continuous=true; recalled,
- * unpinned], functor: src/examples/cartpole_example.jl:3-6; reward = RL.jl's (done ? 0 : 1)
+ * CartPole [3P: ReinforcementLearning.jl 0.11 -> ReinforcementLearningEnvironments,
+ * src/environments/examples/CartPoleEnv.jl: CartPoleEnvParams, _step!(env, a); recalled, unpinned], functor: src/examples/cartpole_example.jl:3-6; reward = RL.jl's (done ? 0 : 1)
  * ====================================================================================== */
 void orc_cartpole_default_params(double *p) {
     p[ORC_XP_GRAVITY] = 9.8; p[ORC_XP_MASSCART] = 1.0; p[ORC_XP_MASSPOLE] = 0.1;
@@ -327,7 +328,9 @@ double orc_rollout_model(orc_env *e, int T, const double *controls, double *traj
 int orc_m_elite(int K, double thr) { return (int)nearbyint(K * (1 - thr)); }       /* policies.jl:437,515 */
 
 /* ======================================================================================
- * dense linear algebra [3P stand-ins]
+ * dense linear algebra [3P stand-ins for the LAPACK calls behind: LinearAlgebra stdlib cholesky.jl
+ * (cholesky(::Symmetric) -> potrf, PosDefException on a non-positive pivot), PDMats 0.11 src/pdmat.jl
+ * (PDMat(Σ) inside Distributions.MvNormal(Σ); inv(::PDMat) for invcov), symmetric.jl (^, eigen)]
  * ====================================================================================== */
 int orc_cholesky_lower(int n, const double *A, double *L) {
     memset(L, 0, sizeof(double) * n * n);
@@ -410,7 +413,8 @@ int orc_sym_eig(int n, const double *A, double *ev, double *V) {
     return 0;
 }
 
-/* LinearAlgebra ^(A::Symmetric-real, p): F=eigen(A); V*Diagonal(l.^p)*V' [3P] */
+/* [3P] LinearAlgebra stdlib, symmetric.jl: ^(A::Symmetric{<:Real}, p::Real): F = eigen(A); all λ >= 0 ->
+ * Symmetric((F.vectors * Diagonal(F.values .^ p)) * F.vectors')   (policies.jl:580 calls it as Σ^-0.5) */
 int orc_sym_pow(int n, const double *A, double p, double *out) {
     double *ev = (double *)malloc(sizeof(double) * n);
     double *V = (double *)malloc(sizeof(double) * n * n);
@@ -486,8 +490,9 @@ void orc_philox_resample_draws(uint64_t seed, uint32_t slo, uint32_t shi, int K,
 }
 
 /* ======================================================================================
- * alias table [3P]: StatsBase.make_alias_table!(w, wsum, a, alias) as used by
- * Distributions.AliasTable(probs) -> Categorical sampler (policies.jl:804-805)
+ * alias table [3P]: StatsBase 0.34 src/sampling.jl make_alias_table!(w, wsum, a, alias) as used by
+ * Distributions 0.25 src/samplers/aliastable.jl AliasTable(probs) -- the sampler of Categorical(ws)
+ * (policies.jl:804-805); rand(rng, s::AliasTable): i = rand(rng, 1:n); rand(rng) < s.accept[i] ? i : s.alias[i]
  * ====================================================================================== */
 void orc_make_alias_table(const double *w, double wsum, int n, double *a, int32_t *alias) {
     double ac = n / wsum;
@@ -637,7 +642,8 @@ void orc_roll_U(orc_policy *pol, const double *wc, double *control) {
  * not dominated by serial linear algebra. */
 static int g_dense_threads = 1;
 
-/* E = L*Z (unwhiten!, [3P] PDMats), Z and E cs x K col-major */
+/* E = L*Z, Z and E cs x K col-major.  [3P] Distributions 0.25 src/multivariate/mvnormal.jl: _rand!(rng, d::MvNormal, x) =
+ * unwhiten!(d.Σ, randn!(rng, x)) (+ μ = 0); PDMats 0.11 src/pdmat.jl: unwhiten!(r, a::PDMat, x) = lmul!(chol_lower(a.chol), r) */
 static void lmul_LZ(int cs, int K, const double *L, const double *Z, double *E) {
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(g_dense_threads) schedule(static)
@@ -665,7 +671,8 @@ static void sortperm(const double *c, int K, int *order) {
     free(t);
 }
 
-/* CovarianceEstimation.cov(SimpleCovariance(), X) with X = elite' (m x cs): uncorrected [3P] */
+/* [3P] CovarianceEstimation 0.2 src/basicmethods.jl: cov(::SimpleCovariance, X; dims = 1) with X = elite' (m x cs):
+ * corrected = false by default, i.e. divide by m */
 static void cov_mle_cols(int cs, int m, const double *X /* cs x m col-major */, double *mean, double *S) {
     for (int r = 0; r < cs; ++r) {
         double s = 0.0;
@@ -680,7 +687,8 @@ static void cov_mle_cols(int cs, int m, const double *X /* cs x m col-major */, 
         }
 }
 
-/* LinearShrinkage(DiagonalUnequalVariance(), :ss) [3P, recalled from Schaefer & Strimmer 2005,
+/* [3P] CovarianceEstimation 0.2 src/linearshrinkage.jl: cov(LinearShrinkage(DiagonalUnequalVariance(), :ss), X) --
+ * linear_shrinkage(::DiagonalUnequalVariance, Xc, S, :ss, ...) [recalled from Schaefer & Strimmer 2005,
  * target D: shrink off-diagonals only; lambda* = sum_{i!=j} Var^(r_ij) / sum_{i!=j} r_ij^2 computed on
  * standardised data; S_shrunk = lambda*diag(S) + (1-lambda)*S].  UNPINNED. */
 static void cov_ss_cols(int cs, int m, const double *X, double *mean, double *S) {
@@ -709,7 +717,7 @@ static void cov_ss_cols(int cs, int m, const double *X, double *mean, double *S)
     free(sd);
 }
 
-/* LinearShrinkage(DiagonalUnequalVariance(), :lw) [3P, recalled: Ledoit & Wolf intensity for the diagonal target on the
+/* [3P] CovarianceEstimation 0.2 src/linearshrinkage.jl: LinearShrinkage(DiagonalUnequalVariance(), :lw) [recalled: Ledoit & Wolf intensity for the diagonal target on the
  * UNstandardised data: lambda* = sum_{i!=j} Var^(s_ij) / sum_{i!=j} s_ij^2, Var^(s_ij) = n/(n-1)^3 sum_k (w_kij - s_ij)^2,
  * w_kij = xc_ki xc_kj].  UNPINNED. */
 static void cov_lw_cols(int cs, int m, const double *X, double *mean, double *S) {
@@ -734,7 +742,7 @@ static void cov_lw_cols(int cs, int m, const double *X, double *mean, double *S)
             if (a != b) S[a + (size_t)b * cs] *= (1 - lam);
 }
 
-/* LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas) [3P, Chen, Wiesel, Eldar & Hero 2010, eqs. (17) and (23)]:
+/* [3P] CovarianceEstimation 0.2 src/linearshrinkage.jl: LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas) [Chen, Wiesel, Eldar & Hero 2010, eqs. (17) and (23)]:
  * F = tr(S)/p I;  rblw: lambda = ((n-2)/n tr(S^2) + tr(S)^2) / ((n+2)(tr(S^2) - tr(S)^2/p));
  * oas: lambda = ((1-2/p) tr(S^2) + tr(S)^2) / ((n+1-2/p)(tr(S^2) - tr(S)^2/p)); clamp to [0,1];  S <- (1-lambda) S + lambda F.
  * UNPINNED. */
@@ -753,7 +761,8 @@ static void cov_common_cols(int cs, int m, const double *X, double *mean, double
             S[a + (size_t)b * cs] = (1 - lam) * S[a + (size_t)b * cs] + ((a == b) ? lam * f : 0.0);
 }
 
-/* StatsBase.mean_and_cov(E, pw::ProbabilityWeights, 2) -- weighted, uncorrected [3P] */
+/* [3P] StatsBase 0.34 src/cov.jl: mean_and_cov(x::DenseMatrix, w::AbstractWeights, dims = 2; corrected = false):
+ * m = mean(x, w, dims = 2); scattermat(x, w, mean = m, dims = 2) / sum(w)   (policies.jl:730-733) */
 static void wmean_wcov(int cs, int K, const double *E, const double *w, double *mu, double *S) {
     double wsum = 0.0;
     for (int k = 0; k < K; ++k) wsum += w[k];
@@ -896,7 +905,7 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
                 orc_make_alias_table(ws, 1.0, K, acc, al);
                 orc_alias_sample(acc, al, K, nz->res_i0 + (size_t)(n - 1) * K, nz->res_u + (size_t)(n - 1) * K, K, idx);
                 if (out->res_idx0) memcpy(out->res_idx0 + (size_t)(n - 1) * K, idx, sizeof(int32_t) * K);
-                /* mean_and_cov(E', 2): unweighted mean, corrected covariance [3P] */
+                /* [3P] StatsBase 0.34 src/cov.jl: mean_and_cov(x, dims = 2; corrected = true): unweighted mean, covariance / (K-1) */
                 for (int r = 0; r < cs; ++r) {
                     double s = 0.0;
                     for (int k = 0; k < K; ++k) s += E[r + (size_t)idx[k] * cs];
@@ -1114,7 +1123,7 @@ int orc_run_trial_noise(orc_policy *pol, orc_env *env, uint64_t seed, int num_st
     return status;
 }
 
-/* src/examples/example_utils.jl:2-10 (p=0.05, q=0.5); quantile(x,0.5) = type-7 median [3P] */
+/* src/examples/example_utils.jl:2-10 (p=0.05, q=0.5); quantile(x,0.5) = Statistics stdlib quantile, type 7 (linear interpolation) [3P] */
 static int cmp_d(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
 void orc_quantile_ci(const double *x, int n, double *lo, double *med, double *hi) {
     double *s = (double *)malloc(sizeof(double) * n);

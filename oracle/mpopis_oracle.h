@@ -12,7 +12,12 @@
  * anchored by hand-derivable known-answer tests (tests/test_oracle_kat.py) and by an independent
  * NumPy re-derivation of the closed-form pieces (oracle/np_rederive.py).  Third-party semantics
  * (Distributions / StatsBase / PDMats / CovarianceEstimation / ReinforcementLearning.jl) are
- * restated from their published algorithms as recalled; each such spot is marked [3P].
+ * restated from their published algorithms as recalled; each such spot is marked [3P] and names the
+ * upstream package (version from the reference's Project.toml [compat]), file and function it stands for.
+ *
+ * PINNING IS A ONE-COMMAND JOB once Julia is available: `julia --project=<MPOPIS> tools/gen_golden.jl` writes
+ * tests/golden/julia_*.json (inputs, the normals / resampling draws the reference consumed, its outputs), and
+ * tests/test_julia_golden.py then checks THIS file against them (it skips, loudly, while they are absent).
  */
 #ifndef MPOPIS_ORACLE_H
 #define MPOPIS_ORACLE_H
