@@ -52,13 +52,21 @@ template <class T> static int dalloc(mpopis_handle* h, T** p, size_t n) {
     return 0;
 }
 
+static const char* kClassNames[] = {"rollout", "sample", "potrf", "reweight", "moments", "select", "other"};
+
 void mpopis_handle::time_begin(int slot) {
+    cur_class = slot;
     ev_open = timing && (timing_mask & (1 << slot)) && ev_used + 2 <= (int)events.size();
     if (!ev_open) return;
     (void)hipEventRecord(events[ev_used], stream);
     ev_slot.push_back(slot);
 }
 void mpopis_handle::time_end() {
+    if (debug_launch && launch_err.empty()) {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) launch_err = std::string("kernel class '") + kClassNames[cur_class] + "': " + hipGetErrorString(e);
+    }
     if (!ev_open) return;
     (void)hipEventRecord(events[ev_used + 1], stream);
     ev_used += 2;
@@ -121,7 +129,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
         HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
         HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_skew[i], hipEventDisableTiming));
     }
-    if (const char* e = getenv("MPOPIS_NSPLIT")) h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e)));   // experiments (tools/ab)
+    if (const char* e = getenv("MPOPIS_DEBUG_LAUNCH")) h->debug_launch = atoi(e) != 0;
+    if (const char* e = getenv("MPOPIS_NSPLIT")) { h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e))); h->split_auto = false; }   // experiments (tools/ab)
     h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
     h->as = car ? 2 * cfg->num_cars : 1;
     h->ss = car ? 8 * cfg->num_cars : (cfg->env_kind == MPOPIS_ENV_CARTPOLE ? 4 : 2);
@@ -491,7 +500,9 @@ int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double*
 
 int mpopis_set_overlap(mpopis_handle* h, int32_t on) {
     if (!h) return MPOPIS_ERR_ARG;
+    if (on < 0) { h->nsplit = 2; h->split_auto = true; return MPOPIS_OK; }                   // back to the default policy
     h->nsplit = on ? std::max(2, std::min((int)mpopis_handle::kMaxSplit, (int)on)) : 1;      // 1: two halves; 2..4: that many parts
+    h->split_auto = false;
     return MPOPIS_OK;
 }
 
@@ -511,7 +522,7 @@ int mpopis_timing_read(mpopis_handle* h, char* names, int32_t names_cap, double*
     if (!h || !n) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    static const char* kNames[] = {"rollout", "sample", "potrf", "reweight", "moments", "select", "other"};
+    const char* const* kNames = kClassNames;
     const int nslots = 7;
     std::vector<double> ms(nslots, 0.0); std::vector<int64_t> cnt(nslots, 0);
     for (size_t i = 0; i < h->ev_slot.size(); ++i) {
@@ -594,10 +605,16 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
 // (Cholesky: nb workgroups on 256 CUs; weights; the scatter's finish), the other half's rollout / sampler fills the chip.
 // Per-slot results are bit-identical to the single-stream order (every kernel is slot-independent and deterministic).
 int mpopis_handle::policy_step_enqueue(bool injected) {
-    const int B0 = B, np = std::min(nsplit, B0);
+    // default policy: split only when the rollout launch fills the chip at least twice over (>= 2 waves per SIMD: 2048 waves of
+    // 64 samples).  Below that every kernel of the chain is latency-bound and two chains only compete for the same critical path
+    // (measured: C4, 8 trials x 3 cars: 11.9 ms single stream, 12.1 ms in two parts; C5, 64 trials: 6.79 -> 6.42 ms).
+    const int B0 = B;
+    const long long rollout_waves = (long long)B0 * ((K + 63) / 64) * std::max(1, env.ncars);
+    const int np = (split_auto && rollout_waves < 2048) ? 1 : std::min(nsplit, B0);
     if (np < 2) {
         const int rc = step_enqueue_view(injected, nullptr, nullptr);
         mpc_step += 1;
+        if (!rc && !launch_err.empty()) { err = launch_err; launch_err.clear(); return MPOPIS_ERR_HIP; }
         return rc;
     }
     (void)hipEventRecord(ev_fork, stream);                      // the other streams start after everything already queued on the main stream
@@ -616,6 +633,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     shift_slots(-b0); B = B0; stream = main_stream;
     for (int p = 1; p < np; ++p) (void)hipStreamWaitEvent(stream, ev_join[p - 1], 0);   // later work on the main stream sees every part
     mpc_step += 1;
+    if (!rc && !launch_err.empty()) { err = launch_err; launch_err.clear(); return MPOPIS_ERR_HIP; }
     return rc;
 }
 

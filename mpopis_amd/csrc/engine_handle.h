@@ -13,6 +13,7 @@ struct mpopis_handle {
     hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {nullptr, nullptr, nullptr}, ev_skew[kMaxSplit - 1] = {nullptr, nullptr, nullptr};
     int nsplit = 2;                                                            // parts the batch is split into (1 = single stream)
+    bool split_auto = true;                                                    // split only when the batch is large enough to be throughput-bound
     mpopis::EnvDesc env{};
     std::string err;
     std::vector<void*> allocs;
@@ -53,6 +54,9 @@ struct mpopis_handle {
     double* h_pin = nullptr;          // pinned staging for the small per-step outputs (control, iters)
     // timing
     bool timing = false, ev_open = false; int timing_mask = ~0;
+    // MPOPIS_DEBUG_LAUNCH=1: after every kernel class of a policy step, hipGetLastError + stream sync, so that a failing
+    // launch / faulting kernel is reported with the class it belongs to (release runs check once per call)
+    bool debug_launch = false; int cur_class = 0; std::string launch_err;
     std::vector<hipEvent_t> events; std::vector<int> ev_slot; int ev_used = 0;
 
     void time_begin(int slot);

@@ -163,3 +163,22 @@ def test_gather_summary_through_the_abi(M):
     parts = eng.gather_summary(rec[:0], 3)                              # a rank without trials
     assert parts[0].shape == (0, RECORD_LEN)
     eng.close()
+
+
+def test_debug_launch_checks_and_two_handles_one_device(M, monkeypatch):
+    """MPOPIS_DEBUG_LAUNCH=1 checks hipGetLastError + syncs after every kernel class (same results as a release run); two
+    handles on device 0 used in interleaved order get their large-LDS kernels configured per device, not per process."""
+    from mpopis_amd.engine import Engine
+    kw = dict(lam=10.0, ais_its=3, lam_ais=20.0, cov=[0.0625, 0.1], seed=5)
+    a = Engine("car", 1, "musigmaaismppi", 512, 50, batch=2, **kw)          # cs = 100: 100 KiB LDS Cholesky, 96 KiB scatter
+    monkeypatch.setenv("MPOPIS_DEBUG_LAUNCH", "1")
+    b = Engine("car", 1, "musigmaaismppi", 512, 50, batch=2, **kw)
+    monkeypatch.delenv("MPOPIS_DEBUG_LAUNCH")
+    c = Engine("car", 1, "pmcmppi", 512, 50, batch=2, **kw)
+    rb = b.policy_step(None)
+    rc_ = c.policy_step(None)
+    ra = a.policy_step(None)
+    assert np.array_equal(ra["control"], rb["control"]) and np.array_equal(ra["cost"], rb["cost"])
+    assert np.all(np.isfinite(rc_["control"]))
+    for e in (a, b, c):
+        e.close()

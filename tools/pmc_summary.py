@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc passes (gpurun_out/pmc_r01/*/pmc_counter_collection.csv) per kernel:
-mean counter value per dispatch and mean duration.  Writes profiles/r01l_pmc_summary.csv and
+mean counter value per dispatch and mean duration.  Writes profiles/r02_pmc_summary.csv and
 profiles/pmc_rollout.json (HBM bytes per launch of the rollout kernel, used by bench.py)."""
 import csv, glob, json, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01"
@@ -21,7 +21,7 @@ for k in sorted(acc, key=lambda k: -sum(dur[k])):
         row[c] = sum(v) / len(v) if v else ""
     rows.append(row)
 os.makedirs("profiles", exist_ok=True)
-with open("profiles/r01l_pmc_summary.csv", "w", newline="") as fo:
+with open("profiles/r02_pmc_summary.csv", "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=["kernel", "dispatches_per_pass", "avg_us"] + names)
     w.writeheader()
     w.writerows(rows)
@@ -33,18 +33,28 @@ if ro:
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts half the bytes of a
     # wide (16 B/lane) coalesced stream; this kernel's E loads are 8 B/lane (512 B per wave instruction) -- calibrated below
     # against the known byte count (the kernel reads E once: B*cs*K*8 bytes).
-    B, cs, K = 64, 100, 4096
+    cs, K = 100, 4096
+    # trials per launch: 64 on one stream, 32 in the default two-stream schedule -- read it off the dispatch's grid (K/256 x B workgroups of 256)
+    B = 64
+    try:
+        tr = list(csv.DictReader(open(glob.glob(os.path.join(root, "*", "pmc_counter_collection.csv"))[0])))
+        g = [int(x["Grid_Size"]) for x in tr if "k_rollout_car" in x["Kernel_Name"] and x.get("Grid_Size")]
+        if g:
+            B = max(1, round(sum(g) / len(g) / K))
+    except Exception:
+        pass
     known_read = B * cs * K * 8
     fetch_kib, write_kib = r.get("FETCH_SIZE") or 0.0, r.get("WRITE_SIZE") or 0.0
     out = {"kernel": r["kernel"], "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
            "known_read_bytes_per_launch": known_read, "fetch_raw_bytes": fetch_kib * 1024,
            "fetch_calibration_ratio_known_over_raw": known_read / (fetch_kib * 1024) if fetch_kib else None,
-           "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+           "trials_per_launch": B, "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,
+           "hbm_bytes_per_rollout": (2 * fetch_kib * 1024 + write_kib * 1024) / (B * K),
            "valu_insts_per_rollout": (r.get("SQ_INSTS_VALU") or 0.0) / (B * K / 64.0),
            "fp64_valu_insts_per_rollout": sum((r.get(c) or 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")) / (B * K / 64.0),
            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
            "valu_busy_frac": ((r.get("SQ_ACTIVE_INST_VALU") or 0.0) * 4.0) / (((r.get("GRBM_GUI_ACTIVE") or 1.0) / 8.0) * 1024.0),
            "effective_clock_ghz": ((r.get("GRBM_GUI_ACTIVE") or 0.0) / 8.0) / (r["avg_us"] * 1e3),
-           "note": "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md §HBM); 64 trials, K=4096, cs=100"}
+           "note": "hbm_bytes_per_launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md §HBM); %d trials per launch, K=4096, cs=100" % B}
     json.dump(out, open("profiles/pmc_rollout.json", "w"), indent=1)
     print(out)
