@@ -148,6 +148,7 @@ void launch_alias_sample(const double* accept, const int32_t* alias, const int32
 
 // kernels_cma.hip
 // kernels_invsqrt.hip: y = A^-1/2 b (Lanczos + quadrature) and fro = tr(A^-1) = scale * ||L^-1||_F^2 with L = chol(scale * A)
+constexpr size_t kInvsqrtPadDoubles = 512;
 size_t invsqrt_workspace_doubles(int B, int n);
 int invsqrt_max_n();
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,

@@ -149,7 +149,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     int rc = 0;
     rc |= dalloc(h, &h->d_x, (size_t)B * h->ss); rc |= dalloc(h, &h->d_xext, (size_t)B * kMaxCars * kCarExt); rc |= dalloc(h, &h->d_t, B); rc |= dalloc(h, &h->d_done, B);
     rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
-    rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
+    rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn + kInvsqrtPadDoubles); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
     rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
     rc |= dalloc(h, &h->d_Z, (size_t)B * cs * K); rc |= dalloc(h, &h->d_E, (size_t)B * cs * K);
     rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);

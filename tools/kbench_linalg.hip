@@ -1,0 +1,55 @@
+// kbench_linalg.hip -- standalone timing of the one-workgroup-per-slot linear-algebra kernels at CMA sizes (dev tool, not shipped).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench_linalg.hip mpopis_amd/lib/obj/kernels_linalg.o mpopis_amd/lib/obj/kernels_invsqrt.o -o tools/kbench_linalg_bin
+#include "../mpopis_amd/csrc/engine.h"
+#include <cstdio>
+#include <vector>
+#include <random>
+#include <cmath>
+using namespace mpopis;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+template <class F> float timeit(F f, int reps, hipStream_t s) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipStreamSynchronize(s);
+    hipEventRecord(a, s);
+    for (int i = 0; i < reps; ++i) f();
+    hipEventRecord(b, s); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / reps * 1e3f;
+}
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 300;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const size_t nn = (size_t)n * n;
+    std::mt19937_64 rng(1); std::normal_distribution<double> nd;
+    // CMA-like covariance: two-eigenvalue block diagonal + a few rank-one terms + a constant added to every entry
+    std::vector<double> A(nn * B, 0.0), bv((size_t)B * n);
+    for (int b = 0; b < B; ++b) {
+        double* a = A.data() + b * nn;
+        for (int i = 0; i < n; ++i) a[i + (size_t)i * n] = (i & 1) ? 0.1 : 0.0625;
+        for (int t = 0; t < 6; ++t) {
+            std::vector<double> p(n); for (auto& v : p) v = nd(rng) * 0.05;
+            for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) a[i + (size_t)j * n] = 0.99 * a[i + (size_t)j * n] + 1e-3 * p[i] * p[j] + 2e-5;
+        }
+        for (int i = 0; i < n; ++i) bv[(size_t)b * n + i] = nd(rng);
+    }
+    double *dA, *dL, *db, *dpart, *dV, *dy, *dfro; int *dstatus, *dact, *dm;
+    CK(hipMalloc(&dA, (nn * B + kInvsqrtPadDoubles) * 8)); CK(hipMalloc(&dL, nn * B * 8)); CK(hipMalloc(&db, (size_t)B * n * 8));
+    CK(hipMalloc(&dpart, (size_t)B * ((n + 15) / 16) * 8)); CK(hipMalloc(&dV, invsqrt_workspace_doubles(B, n) * 8));
+    CK(hipMalloc(&dy, (size_t)B * n * 8)); CK(hipMalloc(&dfro, B * 8)); CK(hipMalloc(&dstatus, B * 4)); CK(hipMalloc(&dact, B * 4)); CK(hipMalloc(&dm, B * 4));
+    CK(hipMemcpy(dA, A.data(), nn * B * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, bv.data(), (size_t)B * n * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dstatus, 0, B * 4));
+    std::vector<int> ones(B, 1); CK(hipMemcpy(dact, ones.data(), B * 4, hipMemcpyHostToDevice));
+    printf("B=%d n=%d\n", B, n);
+    printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s); }, 20, s));
+    {
+        std::vector<double> L(nn); CK(hipMemcpy(L.data(), dL, nn * 8, hipMemcpyDeviceToHost));
+        double err = 0; for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k <= j; ++k) v += L[i + (size_t)k * n] * L[j + (size_t)k * n]; err = fmax(err, fabs(v - A[i + (size_t)j * n])); }
+        double up = 0; for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) up = fmax(up, fabs(L[i + (size_t)j * n]));
+        printf("   potrf max |LL'-A| = %.3e, max |upper| = %.1e\n", err, up);
+    }
+    printf("trtri_fro + lanczos   %8.1f us\n", timeit([&] { launch_invsqrt_vec(dA, dL, nn, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s); }, 20, s));
+    std::vector<int> m(B), st(B); std::vector<double> fro(B);
+    CK(hipMemcpy(m.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fro.data(), dfro, B * 8, hipMemcpyDeviceToHost));
+    printf("   Lanczos steps m = %d %d ..., status %d, tr(A^-1) = %.6e\n", m[0], m[B > 1 ? 1 : 0], st[0], fro[0]);
+    return 0;
+}
