@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # development aids for exercising the N > 1 control flow on a 1-GPU box (never used by the driver): all ranks on cuda:0 over gloo.
+    # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--same-gpu", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,12 +107,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
+    cdev = "cuda" if args.backend == "nccl" else "cpu"        # where the small torch.distributed tensors live
     from mpopis_amd import build
     if rank == 0:
         build.build()
@@ -140,7 +150,7 @@ def main():
             can = 1
         except Exception:                            # noqa: BLE001
             can = 0
-        flag = torch.tensor([can], device="cuda")
+        flag = torch.tensor([can], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             return "librccl not loadable behind the ABI on some rank"
@@ -156,7 +166,7 @@ def main():
         th.start()
         th.join(timeout_s)
         good = 1 if res.get("ok") else 0
-        flag = torch.tensor([good], device="cuda")
+        flag = torch.tensor([good], device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             return None
@@ -175,7 +185,7 @@ def main():
             rec[:, :2] = Uh[:, :2]; rec[:, 2] = np.linalg.norm(Uh, axis=1); rec[:, 3] = float(rank)
             return e.gather_summary(rec, nb)
         rec = torch.tensor(np.concatenate([Uh[:, :2], np.linalg.norm(Uh, axis=1, keepdims=True), np.full((nb, 1), float(rank))], 1),
-                           device="cuda", dtype=torch.float64)
+                           device=cdev, dtype=torch.float64)
         gl = [torch.zeros_like(rec) for _ in range(world)] if rank == 0 else None
         dist.gather(rec, gl, dst=0)
         return gl
@@ -191,7 +201,7 @@ def main():
         summary_gather(eng)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -225,7 +235,7 @@ def main():
         _, rl_s = eng_s.bench_policy_steps(args.steps)
         summary_gather(eng_s)
         sync()
-        dts = torch.tensor([time.perf_counter() - t0s], device="cuda", dtype=torch.float64)
+        dts = torch.tensor([time.perf_counter() - t0s], device=cdev, dtype=torch.float64)
         dist.all_reduce(dts, op=dist.ReduceOp.MAX)
         dts = float(dts.item())
         strong = {"scaling": "strong", "total_trials": TRIALS_PER_GPU, "trials_per_gpu": Bs, "value": rl_s * world / dts, "unit": "rollouts/s",

@@ -1,0 +1,39 @@
+"""bench.py's N > 1 control flow, exercised on ONE GPU: two ranks over gloo, both on cuda:0 (development flags of bench.py).
+RCCL refuses two ranks on one device, so this run also covers the guarded fall-back from the ABI gather
+(mpopis_gather_summary) to torch.distributed's gather; on a real multi-GPU node the ABI path is taken.  Checks the contract
+fields of the JSON line, the weak/strong pair and that both ranks' trials are accounted for."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_bench_two_ranks_on_one_gpu():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "rollouts/s"
+    assert d["config"]["trials_per_gpu"] == 64 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    # whole-job value: both ranks' rollouts over the max time
+    per_step = 2 * 64 * 10 * 4096
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    s = d["strong_scaling"]
+    assert s["total_trials"] == 64 and s["trials_per_gpu"] == 32 and s["value"] > 0
+    assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
+    r = d["roofline"]
+    assert r["rollouts_per_launch"] * r["launches"] == 64 * 10 * 4096 * 2          # per-launch accounting matches the schedule
+    assert 0 < r["frac"] < 1 and 0 < r["isolated"]["frac"] < 1
