@@ -75,6 +75,32 @@ struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[
     const int* nbr_idx; const double* nbr_dist; int nbrw;
 };
 constexpr int kTrackNbrW = 16;
+// Row i of nbr_dist has one spare slot (index nbrw): it holds ring_r2[i] = (1 - 1e-9) x the squared distance from q_i to the nearest
+// track point that is NOT one of its ring neighbours {i-1, i, i+1} (+inf when there is none).  If a position p satisfies
+// 4 |p - q_i|^2 < ring_r2[i], every non-ring point j is farther from p than q_i is (|p - q_j| >= |q_j - q_i| - |p - q_i| > |p - q_i|),
+// so the nearest point is one of the three ring candidates -- the common case for a car that moved <= 3 m since the last step.
+
+}  // namespace mpopis
+#include <algorithm>
+#include <utility>
+#include <vector>
+namespace mpopis {
+// host: neighbour tables of the anchored nearest-point search (row stride W + 1, see Track) for P points; W = min(kTrackNbrW, P)
+inline void build_track_tables(int P, const double* x, const double* y, std::vector<double>& nd, std::vector<int>& ni) {
+    const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
+    nd.assign((size_t)P * S, 0.0); ni.assign((size_t)P * S, 0);
+    for (int i = 0; i < P; ++i) {
+        std::vector<std::pair<double, int>> v(P);
+        for (int j = 0; j < P; ++j) v[j] = {sqrt((x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i])), j};
+        v[i].first = -1.0;                                       // rank 0 = the point itself
+        std::sort(v.begin(), v.end());
+        for (int c = 0; c < W; ++c) { nd[(size_t)i * S + c] = std::max(v[c].first, 0.0); ni[(size_t)i * S + c] = v[c].second; }
+        const int im = (i == 0) ? P - 1 : i - 1, ip = (i == P - 1) ? 0 : i + 1;
+        double r2 = INFINITY;
+        for (int j = 0; j < P; ++j) if (j != i && j != im && j != ip) r2 = fmin(r2, (x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i]));
+        nd[(size_t)i * S + W] = r2 * (1.0 - 1e-9);
+    }
+}
 
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 MP_HD double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
@@ -347,19 +373,40 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
     int mi = -1;
     double best = 0.0;
     const int a0 = anchor ? *anchor : -1;
+    double p1x = 0.0, p1y = 0.0, pmx = 0.0, pmy = 0.0, ppx = 0.0, ppy = 0.0;      // nearest point, its ring predecessor / successor
+    bool have_pts = false;
     if (__builtin_expect(a0 >= 0 && tk.nbr_idx, 1)) {
         const int S = tk.nbrw + 1;
-        mi = a0;
-        best = fma(tk.y[a0], m2y, fma(tk.x[a0], m2x, tk.n2[a0]));
-        const double bound = 2.0 * fast_sqrt(fmax(best + fma(px, px, py * py), 0.0)) + 1e-6;
-        bool closed = false;
-        for (int c = 1; c < tk.nbrw; ++c) {
-            if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
-            const int j = tk.nbr_idx[a0 * S + c];
-            const double d = fma(tk.y[j], m2y, fma(tk.x[j], m2x, tk.n2[j]));
-            if (d < best || (d == best && j < mi)) { best = d; mi = j; }
+        // ring candidates {a0-1, a0, a0+1}: all addresses known up front (one LDS round trip), no list indirection
+        const int am = (a0 == 0) ? tk.P - 1 : a0 - 1, ap = (a0 == tk.P - 1) ? 0 : a0 + 1;
+        const double x0 = tk.x[a0], y0 = tk.y[a0], xm = tk.x[am], ym = tk.y[am], xp = tk.x[ap], yp = tk.y[ap];
+        const double d0 = fma(y0, m2y, fma(x0, m2x, tk.n2[a0]));
+        const double D02 = d0 + fma(px, px, py * py);                        // |p - q_a0|^2
+        if (__builtin_expect(4.0 * D02 < tk.nbr_dist[a0 * S + tk.nbrw], 1)) {  // certified: no non-ring point can be nearer (see Track)
+            const double dm = fma(ym, m2y, fma(xm, m2x, tk.n2[am])), dp = fma(yp, m2y, fma(xp, m2x, tk.n2[ap]));
+            mi = a0; best = d0;
+            if (dm < best || (dm == best && am < mi)) { best = dm; mi = am; }    // first minimum: ties -> lowest index, like findmin
+            if (dp < best || (dp == best && ap < mi)) { best = dp; mi = ap; }
+            // the nearest point's own ring neighbours: two of the three are already here, the third is one more point
+            const int e = (mi == am) ? ((am == 0) ? tk.P - 1 : am - 1) : ((ap == tk.P - 1) ? 0 : ap + 1);
+            const double xe = tk.x[e], ye = tk.y[e];
+            if (mi == a0) { p1x = x0; p1y = y0; pmx = xm; pmy = ym; ppx = xp; ppy = yp; }
+            else if (mi == am) { p1x = xm; p1y = ym; pmx = xe; pmy = ye; ppx = x0; ppy = y0; }
+            else { p1x = xp; p1y = yp; pmx = x0; pmy = y0; ppx = xe; ppy = ye; }
+            have_pts = true;
+        } else {
+            // far from the anchor (or a track that folds back on itself): scan the anchor's neighbour list up to the triangle bound
+            mi = a0; best = d0;
+            const double bound = 2.0 * fast_sqrt(fmax(D02, 0.0)) + 1e-6;
+            bool closed = false;
+            for (int c = 1; c < tk.nbrw; ++c) {
+                if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
+                const int j = tk.nbr_idx[a0 * S + c];
+                const double d = fma(tk.y[j], m2y, fma(tk.x[j], m2x, tk.n2[j]));
+                if (d < best || (d == best && j < mi)) { best = d; mi = j; }
+            }
+            if (__builtin_expect(!closed && tk.nbrw < tk.P, 0)) mi = -1;   // list exhausted before the bound: full scan
         }
-        if (__builtin_expect(!closed && tk.nbrw < tk.P, 0)) mi = -1;   // list exhausted before the bound: full scan
     }
     if (__builtin_expect(mi < 0, 0)) {
         mi = 0;
@@ -372,16 +419,18 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
         }
     }
     if (anchor) *anchor = mi;
-    const int im = (mi == 0) ? tk.P - 1 : mi - 1;                              // mod1 :75-76
-    const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
-    const double p1x = tk.x[mi], p1y = tk.y[mi];
-    const double ax = tk.x[im] - px, ay = tk.y[im] - py, bx = tk.x[ip] - px, by = tk.y[ip] - py;
+    if (!have_pts) {
+        const int im = (mi == 0) ? tk.P - 1 : mi - 1;                          // mod1 :75-76
+        const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
+        p1x = tk.x[mi]; p1y = tk.y[mi]; pmx = tk.x[im]; pmy = tk.y[im]; ppx = tk.x[ip]; ppy = tk.y[ip];
+    }
+    const double ax = pmx - px, ay = pmy - py, bx = ppx - px, by = ppy - py;
     // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone).  Only when the two squares
     // differ by an ulp or two could the rounding of the reference's square roots turn `>` into its tie (-> prev); at that
     // point the position is equidistant from both neighbours to 1e-16 and the reference's own choice is rounding noise.
     const double dm2 = fma(ax, ax, ay * ay), dp2 = fma(bx, bx, by * by);
     const bool prev = dm2 <= dp2;
-    const double p2x = prev ? tk.x[im] : tk.x[ip], p2y = prev ? tk.y[im] : tk.y[ip];
+    const double p2x = prev ? pmx : ppx, p2y = prev ? pmy : ppy;
     const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
     const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
     const double ex = (p1x + t * vx) - px, ey = (p1y + t * vy) - py;           // :88-89

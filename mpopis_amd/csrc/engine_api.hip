@@ -235,16 +235,10 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     HIPCHK(h, hipMemcpyAsync(d, x, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + P, y, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(d + 2 * P, w, sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
-    // neighbour tables of the anchored nearest-point search: per point the kTrackNbrW closest points (ascending)
-    const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
-    std::vector<double> nd((size_t)P * S, 0.0); std::vector<int> ni((size_t)P * S, 0);
-    for (int i = 0; i < P; ++i) {
-        std::vector<std::pair<double, int>> v(P);
-        for (int j = 0; j < P; ++j) v[j] = {sqrt((x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i])), j};
-        v[i].first = -1.0;                                       // rank 0 = the point itself
-        std::sort(v.begin(), v.end());
-        for (int c = 0; c < W; ++c) { nd[(size_t)i * S + c] = std::max(v[c].first, 0.0); ni[(size_t)i * S + c] = v[c].second; }
-    }
+    // neighbour tables of the anchored nearest-point search (car_dynamics.h: build_track_tables)
+    const int W = std::min<int>(kTrackNbrW, P);
+    std::vector<double> nd; std::vector<int> ni;
+    build_track_tables(P, x, y, nd, ni);
     double* dnd = nullptr; int* dni = nullptr;
     if (dalloc(h, &dnd, nd.size()) || dalloc(h, &dni, ni.size())) return MPOPIS_ERR_HIP;
     HIPCHK(h, hipMemcpyAsync(dnd, nd.data(), sizeof(double) * nd.size(), hipMemcpyHostToDevice, h->stream));

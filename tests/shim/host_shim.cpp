@@ -8,15 +8,8 @@ using namespace mpopis;
 static std::vector<double> g_nd; static std::vector<int> g_ni;
 static Track mk(int P, const double* tx, const double* ty, const double* tw, std::vector<double>& n2) {
     n2.resize(P); for (int i = 0; i < P; ++i) n2[i] = tx[i] * tx[i] + ty[i] * ty[i];
-    const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
-    g_nd.assign((size_t)P * S, 0.0); g_ni.assign((size_t)P * S, 0);
-    for (int i = 0; i < P; ++i) {
-        std::vector<std::pair<double, int>> v(P);
-        for (int j = 0; j < P; ++j) v[j] = {sqrt((tx[j] - tx[i]) * (tx[j] - tx[i]) + (ty[j] - ty[i]) * (ty[j] - ty[i])), j};
-        v[i].first = -1.0;
-        std::sort(v.begin(), v.end());
-        for (int c = 0; c < W; ++c) { g_nd[(size_t)i * S + c] = std::max(v[c].first, 0.0); g_ni[(size_t)i * S + c] = v[c].second; }
-    }
+    const int W = std::min<int>(kTrackNbrW, P);
+    build_track_tables(P, tx, ty, g_nd, g_ni);
     return Track{tx, ty, tw, n2.data(), P, g_ni.data(), g_nd.data(), W};
 }
 extern "C" {
