@@ -71,8 +71,7 @@ void launch_elite_break(const double* cost, const int32_t* order, int B, int K, 
 
 // StatsBase.make_alias_table!(w, 1.0, a, alias): Vose's construction with LIFO stacks of smalls and
 // larges, executed in the reference's exact operation order (the result must be bit-identical for
-// identical w).  Wave 0 classifies with ballots (keeps index order); lane 0 runs the sequential
-// pairing loop keeping the current large in registers (LIFO => it is re-popped immediately).
+// identical w).  The wave classifies with ballots (keeps index order), then runs the pairing loop (see below).
 __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
                                                     int K, const int* active) {
     MPOPIS_HI_PRIO();
@@ -86,27 +85,76 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
     const int lane = threadIdx.x;
     const double ac = (double)K / 1.0;                          // n / wsum
     int kl = 0, ks = 0;
-    for (int i0 = 0; i0 < K; i0 += 64) {
-        const int i = i0 + lane;
-        const double ai = (i < K) ? w[(size_t)b * K + i] * ac : 1.0;
-        if (i < K) { a[i] = ai; al[i] = i; }
-        const unsigned long long ml = __ballot(ai > 1.0), ms = __ballot(ai < 1.0);
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        if (ai > 1.0) larges[kl + __popcll(ml & lt)] = i;
-        else if (ai < 1.0) smalls[ks + __popcll(ms & lt)] = i;
-        kl += __popcll(ml); ks += __popcll(ms);
+    // classification in index order; the loads of 16 rounds (1024 weights) are issued together (a dependent global round trip
+    // costs a lone wave ~1.5 us: 64 of them would be 100 us)
+    for (int c0 = 0; c0 < K; c0 += 64 * 16) {
+        double wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)b * K + min(c0 + 64 * u + lane, K - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = c0 + 64 * u + lane;
+            if (c0 + 64 * u < K) {                                  // wave-uniform
+                const double ai = (i < K) ? wv[u] * ac : 1.0;
+                if (i < K) { a[i] = ai; al[i] = i; }
+                const unsigned long long ml = __ballot(ai > 1.0), ms = __ballot(ai < 1.0);
+                const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                if (ai > 1.0) larges[kl + __popcll(ml & lt)] = i;
+                else if (ai < 1.0) smalls[ks + __popcll(ms & lt)] = i;
+                kl += __popcll(ml); ks += __popcll(ms);
+            }
+        }
     }
     __syncthreads();
-    if (lane == 0) {
-        while (kl > 0 && ks > 0) {
-            const int s = smalls[--ks];
-            const int l = larges[--kl];
-            al[s] = l;
-            const double alv = (a[l] - 1.0) + a[s];
-            a[l] = alv;
-            if (alv > 1.0) larges[kl++] = l; else smalls[ks++] = l;
+    // The pairing loop is sequential by definition (and its order fixes which index a later draw maps to), but a naive
+    // transcription pays ~4 dependent LDS round trips per pairing (0.85 ms at K = 4096).  What the LIFO discipline implies:
+    //   * a large is re-popped until it drops to <= 1, so it can stay in registers while it absorbs smalls;
+    //   * no other large is ever pushed, so the larges stack only shrinks: the wave prefetches its top 64 entries (index and a)
+    //     in one round trip, lane j <- j-th from the top, and walks them with v_readlane;
+    //   * the same for the smalls stack, except that an exhausted large lands on top of it -- that one is kept in registers as the
+    //     `pending` small and is the first thing the next large absorbs, exactly as in the reference.
+    // The sequential part then runs on registers with the reference's operations in the reference's order (same bits); alias[s] = l
+    // is recorded per lane and written when a batch of smalls is retired.
+    {
+        auto rl_d = [](double v, int j) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j)); };
+        int idxS = 0, aliasS = -1, nS = 0, posS = 0;  double valS = 0.0;      // smalls batch: lane j <-> smalls[ks - 1 - j]
+        int idxL = 0, nL = 0, posL = 0;               double valL = 0.0;      // larges batch (already popped: kl excludes it)
+        int pend_idx = -1;                            double pend_val = 0.0;  // exhausted large = top of the smalls stack
+        auto flushS = [&]() { if (lane < posS) al[idxS] = aliasS; ks -= posS; nS = 0; posS = 0; };
+        auto loadS = [&]() { nS = min(64, ks); idxS = (lane < nS) ? smalls[ks - 1 - lane] : 0; valS = (lane < nS) ? a[idxS] : 0.0; posS = 0; };
+        auto loadL = [&]() { nL = min(64, kl); idxL = (lane < nL) ? larges[kl - 1 - lane] : 0; valL = (lane < nL) ? a[idxL] : 0.0; posL = 0; kl -= nL; };
+        while (true) {
+            if (pend_idx < 0 && posS == nS) { flushS(); if (ks == 0) break; loadS(); }        // `ks > 0` of the reference's loop test
+            if (posL == nL) { if (kl == 0) break; loadL(); }                                   // `kl > 0`
+            const int l = __builtin_amdgcn_readlane(idxL, posL);
+            double a_l = rl_d(valL, posL);
+            posL += 1;
+            bool alive = true;
+            if (pend_idx >= 0) {                                                               // s = the large that just became small
+                if (lane == 0) al[pend_idx] = l;
+                a_l = (a_l - 1.0) + pend_val;
+                pend_idx = -1;
+                alive = a_l > 1.0;
+            }
+            bool dry = false;
+            while (alive) {
+                if (posS == nS) { flushS(); if (ks == 0) { dry = true; break; } loadS(); }
+                const double as = rl_d(valS, posS);
+                if (lane == posS) aliasS = l;                                                  // alias[s] = l
+                posS += 1;
+                a_l = (a_l - 1.0) + as;                                                        // a[l] = (a[l] - 1.0) + a[s]
+                alive = a_l > 1.0;
+            }
+            if (lane == 0) a[l] = a_l;
+            if (dry) break;                                                                    // smalls ran out, this large stays > 1
+            pend_idx = l; pend_val = a_l;                                                      // pushed on the smalls
         }
-        for (int i = 0; i < ks; ++i) a[smalls[i]] = 1.0;
+        flushS();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < ks; i += 64) a[smalls[i]] = 1.0;                                // "should be redundant, except for rounding"
+        if (pend_idx >= 0 && lane == 0) a[pend_idx] = 1.0;
     }
     __syncthreads();
     for (int i = lane; i < K; i += 64) { accept[(size_t)b * K + i] = a[i]; alias[(size_t)b * K + i] = al[i]; }
