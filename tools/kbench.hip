@@ -1,5 +1,5 @@
 // kbench.hip -- standalone micro-benchmark of individual engine kernels (dev tool, not shipped).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.hip mpopis_amd/lib/obj/kernels_*.o -o gpurun_out/kbench
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/kbench.hip -o /tmp/kb.o && hipcc --offload-arch=gfx950 /tmp/kb.o mpopis_amd/lib/obj/kernels_{linalg,mfma,sample}.o -o tools/kbench_bin
 #include "../mpopis_amd/csrc/engine.h"
 #include <cstdio>
 #include <vector>
@@ -75,28 +75,6 @@ int main(int argc, char** argv) {
         std::vector<double> S(nn); CK(hipMemcpy(S.data(), dS, nn * 8, hipMemcpyDeviceToHost));
         double err = 0; for (int i = 0; i < cs; i += 7) for (int j = 0; j < cs; j += 5) { double v = 0; for (int k = 0; k < K; ++k) v += Z[(size_t)i * K + k] * Z[(size_t)j * K + k] / K; if (i == j) v += 1e-8; err = fmax(err, fabs(v - S[i + (size_t)j * cs])); }
         printf("   wcov max err = %.3e\n", err);
-    }
-    // Newton-Schulz inverse sqrt
-    {
-        const int iters = 16;
-        double *dC, *dY0, *dY1, *dZ0, *dZ1, *dT, *dcn; unsigned long long* dres;
-        CK(hipMalloc(&dC, nn * B * 8)); CK(hipMalloc(&dY0, nn * B * 8)); CK(hipMalloc(&dY1, nn * B * 8)); CK(hipMalloc(&dZ0, nn * B * 8));
-        CK(hipMalloc(&dZ1, nn * B * 8)); CK(hipMalloc(&dT, nn * B * 8)); CK(hipMalloc(&dcn, B * 8)); CK(hipMalloc(&dres, (iters + 1) * B * 8));
-        // A2: diag-dominant SPD like the CMA covariances
-        std::vector<double> A2(nn * B, 0.0);
-        for (int b = 0; b < B; ++b) for (int i = 0; i < cs; ++i) { A2[b * nn + i + (size_t)i * cs] = (i & 1) ? 0.1 : 0.0625; for (int j = 0; j < i; ++j) { double v = (3e-2 / cs) * sin(i * 0.37 + j * 0.11 + b); A2[b * nn + i + (size_t)j * cs] = v; A2[b * nn + j + (size_t)i * cs] = v; } }
-        CK(hipMemcpy(dA, A2.data(), nn * B * 8, hipMemcpyHostToDevice));
-        float t = timeit([&] { launch_inv_sqrt_spd(dA, dC, dY0, dY1, dZ0, dZ1, dT, dcn, dres, B, cs, iters, dact, s); }, 5, s);
-        std::vector<unsigned long long> res((iters + 1) * B); CK(hipMemcpy(res.data(), dres, res.size() * 8, hipMemcpyDeviceToHost));
-        printf("inv_sqrt_spd (NS, %d iters max) %8.1f us; residual trail b=0:", iters, t);
-        for (int it = 0; it <= iters; ++it) { double r; memcpy(&r, &res[it * B], 8); printf(" %.1e", r); }
-        printf("\n");
-        std::vector<double> C(nn); CK(hipMemcpy(C.data(), dC, nn * 8, hipMemcpyDeviceToHost));
-        double err = 0;   // check C*A*C = I
-        std::vector<double> CA(nn, 0.0);
-        for (int i = 0; i < cs; ++i) for (int j = 0; j < cs; ++j) { double v = 0; for (int k = 0; k < cs; ++k) v += C[i + (size_t)k * cs] * A2[k + (size_t)j * cs]; CA[i + (size_t)j * cs] = v; }
-        for (int i = 0; i < cs; i += 3) for (int j = 0; j < cs; j += 3) { double v = 0; for (int k = 0; k < cs; ++k) v += CA[i + (size_t)k * cs] * C[k + (size_t)j * cs]; err = fmax(err, fabs(v - (i == j))); }
-        printf("   max |C A C - I| = %.3e\n", err);
     }
     return 0;
 }
