@@ -311,12 +311,16 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
     if (__builtin_expect(fabs(dd) > kTinyAngle, 0)) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
+    // carried across sub-steps: r δt (this sub-step's "old yaw rate x δt" is the previous one's dψ), and -- in rollouts, which read
+    // the position only after the action -- the position increments summed before the common factor δt is applied
+    double rdt = r * p.ddt, sx = 0.0, sy = 0.0;
     auto substep = [&]() {
         { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
         if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
+            rdt = r * p.ddt;
             return;
         }
         const double rinv = fast_rcp1(Vx * xq);
@@ -327,12 +331,13 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         const double fyf = tire_poly(clamp_sym(taf, kf.thr), p.Caf, kf);
         const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral ...
         const double flon = fma(fxf, cd, -(fyf * sd));                         // ... and longitudinal component
-        const double rd = r * p.ddt;                                           // old yaw rate x δt
+        const double rd = rdt;                                                 // old yaw rate x δt
         const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));                            // :323,:328
         const double Vx1 = fma(p.k_v, flon + fma(-p.CD1, Vx, fxr0), fma(rd, Vy, Vx));           // :324,:327 (+ drag :308)
         r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));                                            // :322,:326
         Vx = Vx1; Vy = Vy1;
-        const double dpsi = r * p.ddt;
+        rdt = r * p.ddt;
+        const double dpsi = rdt;
         if (PSI) psi += dpsi;                                                  // :329
         double sq, cq;
         sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/32 ...
@@ -346,13 +351,19 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
             if (PSI) psi = fmod(psi, kTwoPi);
         }
         if (PSI) psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);                  // :330 atan(sin,cos)
-        x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                            // :331
-        y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                               // :332
+        if (PSI) {
+            x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                        // :331
+            y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                           // :332
+        } else {
+            sx = fma(Vx, cp, fma(-Vy, sp, sx));                                // Σ (Vx cos ψ - Vy sin ψ); x += δt Σ after the action
+            sy = fma(Vx, sp, fma(Vy, cp, sy));
+        }
     };
     for (int it = 0; it < p.nsub; it += 2) {                                   // two per trip: no loop-carried register copies
         substep();
         if (it + 1 < p.nsub) substep();                                        // (odd sub-step counts: wave-uniform branch)
     }
+    if (!PSI) { x = fma(sx, p.ddt, x); y = fma(sy, p.ddt, y); }
     // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
     double delta = c.delta;
     if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
