@@ -57,6 +57,17 @@ def _gather_records(rec, dist):
     return out[out[:, 0] > 0]
 
 
+def assemble_gathered(parts, world):
+    """Rows of the summary table from what mpopis_gather_summary hands rank 0: parts[g] = (n_g, RECORD_LEN) records of rank g's
+    trials in slot order, i.e. of trials g+1, g+1+world, ... (shard_trials).  Column layout of the result: [trial id, record[0:15],
+    0, Ex Time] -- the sending rank stored its wall time in record slot 15 (the status slot, unused after a successful run)."""
+    rows = []
+    for g, part in enumerate(parts):
+        for i, row in enumerate(np.asarray(part, dtype=np.float64).reshape(-1, RECORD_LEN)):
+            rows.append(np.concatenate([[1 + g + i * world], row[:15], [0.0], [row[15]]]))
+    return np.array(rows).reshape(-1, RECORD_LEN + 2)
+
+
 def shard_trials(num_trials, rank, world):
     """trial k (1-based) -> rank (k-1) mod world; returns this rank's 1-based trial ids."""
     return [k for k in range(1, num_trials + 1) if (k - 1) % world == rank]
@@ -104,11 +115,7 @@ def simulate_car_racing(num_trials=1, num_steps=200, num_cars=1, policy_type="ce
         eng.close()
         if parts is None:
             return None, None
-        rows = []
-        for g, part in enumerate(parts):
-            for i, row in enumerate(part):
-                rows.append(np.concatenate([[1 + g + i * world], row[:15], [0.0], [row[15]]]))
-        allrec = np.array(rows)
+        allrec = assemble_gathered(parts, world)
     else:
         eng.close()
         rec = np.array([np.concatenate([[k], r[i], [ex_time]]) for i, k in enumerate(mine)]).reshape(-1, RECORD_LEN + 2)

@@ -44,3 +44,26 @@ def test_shard_and_gather_world2():
     # rank 0 holds 4 trials, rank 1 holds 3: uneven shards are padded inside _gather_records
     assert list(out[:, 0]) == [1, 2, 3, 4, 5, 6, 7]
     assert np.array_equal(out[:, 1], np.arange(1, 8) * 10.0)
+
+
+def test_assemble_gathered_matches_the_torch_path_layout():
+    """The nccl branch of simulate_car_racing (records through mpopis_gather_summary) and the gloo branch (_gather_records) must
+    build the same table: trial ids from (rank, slot), record fields in place, Ex Time last."""
+    from mpopis_amd.examples import assemble_gathered, shard_trials
+    from mpopis_amd._lib import RECORD_LEN
+    world, num_trials = 3, 8
+    parts = []
+    for g in range(world):
+        mine = shard_trials(num_trials, g, world)
+        rec = np.array([[100.0 * k + f for f in range(RECORD_LEN)] for k in mine]).reshape(-1, RECORD_LEN)
+        rec[:, 15] = 7.0 + g                                   # the rank's wall time travels in the status slot
+        parts.append(rec)
+    out = assemble_gathered(parts, world)
+    out = out[np.argsort(out[:, 0])]
+    assert out.shape == (num_trials, RECORD_LEN + 2)
+    assert list(out[:, 0]) == list(range(1, num_trials + 1))
+    for row in out:
+        k = int(row[0])
+        assert np.array_equal(row[1:16], [100.0 * k + f for f in range(15)])
+        assert row[16] == 0.0 and row[17] == 7.0 + (k - 1) % world
+    assert assemble_gathered([np.zeros((0, RECORD_LEN))] * 2, 2).shape == (0, RECORD_LEN + 2)
