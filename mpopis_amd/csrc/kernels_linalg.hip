@@ -206,13 +206,216 @@ __global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, si
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-resident Cholesky for n <= 128 (every 1-car configuration), one workgroup of 8 waves per matrix.  Same blocked
+// right-looking scheme as k_potrf, but the two serial pieces of a panel -- which bound it: 7 panels x (diagonal block 3.9 us +
+// panel solve 2.9 us) of 63 us at n = 100 -- are reorganised:
+//   * diagonal 16x16 block: lane = (row i, column group g), 4 entries per lane, processed as 4x4 sub-blocks with one LDS
+//     exchange per sub-block column (instead of 15 v_readlane broadcasts per pivot), and the SAME loop carries a second 16x16
+//     block along that ends up as L11^-1 (right-looking forward substitution on the identity);
+//   * panel solve L21 = A21 L11^-T becomes one 16x16x16 product per row tile on the matrix cores (B operand = L11^-1),
+//     instead of a 136-term dependent substitution per row fed by LDS reads.
+// Using the explicit inverse of the (well-conditioned) 16x16 diagonal block costs ~cond(L11) eps in L21, far inside the
+// parity budget (|L L' - A| stays at 1e-16 |A| in tools/kbench_linalg).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
+                                                   int n, int npad, const double* scale, int* status, int* active) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int failed;
+    __shared__ double Lc[2][kNB][5], Rr[2][4][kNB + 1], Li[kNB][kNB + 1];
+    constexpr int NTHR = 512, NW = NTHR / 64;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* Ab = A + (size_t)b * Astride;
+    double* Lb = Lout + (size_t)b * n * n;
+    const double sc = scale ? scale[b] : 1.0;
+    double* W = smem;                                  // [npad][npad] column-major, identity tail beyond n
+    const int ldw = npad, m = npad;
+    if (tid == 0) failed = 0;
+    {   // copy in the lower triangle only (see k_potrf): column pair c (columns c and m-1-c) holds m+1 triangle entries
+        const int npairs2 = m / 2, tchunks = (m + 1 + 63) / 64;
+        for (int c0 = wv * 4; c0 < npairs2; c0 += NW * 4) {
+            for (int tc = 0; tc < tchunks; tc += 2) {
+                double av[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(c0 + (u >> 1), npairs2 - 1), t = min((tc + (u & 1)) * 64 + lane, m);
+                    const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                    av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + (u >> 1), t = (tc + (u & 1)) * 64 + lane;
+                    if (c < npairs2 && t <= m && tc + (u & 1) < tchunks) {
+                        const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                        W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    // diagonal block at j0: L11 -> W, L11^-1 -> Li.  One wave; lane = (row i = li, column group g = lk), entries of columns 4g .. 4g+3.
+    // Processed as a 4 x 4 grid of 4x4 sub-blocks, ONE LDS exchange per sub-block column G (a lone wave issues a dependent
+    // instruction only every ~8 cycles and an LDS round trip costs ~100+: the per-pivot version of this loop took 900 cycles per
+    // pivot).  Per G: every lane gathers the diagonal 4x4 sub-block (v_readlane), factors and inverts it redundantly in registers,
+    // the lanes of column group G turn their row into L (rows below: x T', T = L4^-1), the L column block and the R rows of
+    // group G go through LDS, and every lane updates its trailing entries and its rows of R = (rows of L11^-1 in the making).
+    auto factor_diag_inv = [&](int j0) {
+        const int i = li, g = lk;
+        double e[4], mi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { e[q] = W[(size_t)(j0 + i) + (size_t)(j0 + 4 * g + q) * ldw]; mi[q] = (i == 4 * g + q) ? 1.0 : 0.0; }
+        bool bad = false;
+        auto rsqrt_full = [&](double piv) {                     // v_rsq_f64 seed + 2 Newton steps (full precision)
+            if (!(piv > 0.0)) bad = true;
+            double rs = __builtin_amdgcn_rsq(piv);
+            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+            return rs * fma(-0.5 * piv * rs, rs, 1.5);
+        };
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const int buf = G & 1;
+            // (a) the 4x4 diagonal sub-block (lower part), from lanes (4G + r, G)
+            const double s00 = bcast_lane(e[0], 4 * G + 0 + 16 * G);
+            const double s10 = bcast_lane(e[0], 4 * G + 1 + 16 * G), s11 = bcast_lane(e[1], 4 * G + 1 + 16 * G);
+            const double s20 = bcast_lane(e[0], 4 * G + 2 + 16 * G), s21 = bcast_lane(e[1], 4 * G + 2 + 16 * G), s22 = bcast_lane(e[2], 4 * G + 2 + 16 * G);
+            const double s30 = bcast_lane(e[0], 4 * G + 3 + 16 * G), s31 = bcast_lane(e[1], 4 * G + 3 + 16 * G), s32 = bcast_lane(e[2], 4 * G + 3 + 16 * G),
+                         s33 = bcast_lane(e[3], 4 * G + 3 + 16 * G);
+            // Cholesky of the sub-block and its inverse T (both lower triangular), in registers
+            const double r0 = rsqrt_full(s00), l00 = s00 * r0, l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
+            const double d1 = fma(-l10, l10, s11), r1 = rsqrt_full(d1), l11 = d1 * r1;
+            const double l21 = fma(-l20, l10, s21) * r1, l31 = fma(-l30, l10, s31) * r1;
+            const double d2 = fma(-l21, l21, fma(-l20, l20, s22)), r2 = rsqrt_full(d2), l22 = d2 * r2;
+            const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
+            const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33))), r3 = rsqrt_full(d3), l33 = d3 * r3;
+            const double t00 = r0, t11 = r1, t22 = r2, t33 = r3;
+            const double t10 = -(l10 * t00) * r1, t21 = -(l21 * t11) * r2, t32 = -(l32 * t22) * r3;
+            const double t20 = -fma(l21, t10, l20 * t00) * r2, t31 = -fma(l32, t21, l31 * t11) * r3;
+            const double t30 = -fma(l32, t20, fma(l31, t10, l30 * t00)) * r3;
+            // (b) column block G of L: the sub-block rows take L4, rows below x T' (x = the row's four entries), rows above 0
+            if (g == G) {
+                const int r = i - 4 * G;
+                double n0, n1, n2, n3;
+                if (r < 0) { n0 = n1 = n2 = n3 = 0.0; }
+                else if (r == 0) { n0 = l00; n1 = n2 = n3 = 0.0; }
+                else if (r == 1) { n0 = l10; n1 = l11; n2 = n3 = 0.0; }
+                else if (r == 2) { n0 = l20; n1 = l21; n2 = l22; n3 = 0.0; }
+                else if (r == 3) { n0 = l30; n1 = l31; n2 = l32; n3 = l33; }
+                else {
+                    n0 = e[0] * t00;
+                    n1 = fma(e[1], t11, e[0] * t10);
+                    n2 = fma(e[2], t22, fma(e[1], t21, e[0] * t20));
+                    n3 = fma(e[3], t33, fma(e[2], t32, fma(e[1], t31, e[0] * t30)));
+                }
+                e[0] = n0; e[1] = n1; e[2] = n2; e[3] = n3;
+                Lc[buf][i][0] = n0; Lc[buf][i][1] = n1; Lc[buf][i][2] = n2; Lc[buf][i][3] = n3;
+            }
+            if ((i >> 2) == G) {                                // R rows of group G, all column groups
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Rr[buf][i & 3][4 * g + q] = mi[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // rows 4G..4G+3 of L11^-1 restricted to this lane's columns: M[k][q] = sum_{k' <= k} T[k][k'] R[4G+k'][4g+q]
+            double M0[4], M1[4], M2[4], M3[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double a0 = Rr[buf][0][4 * g + q], a1 = Rr[buf][1][4 * g + q], a2 = Rr[buf][2][4 * g + q], a3 = Rr[buf][3][4 * g + q];
+                M0[q] = t00 * a0;
+                M1[q] = fma(t11, a1, t10 * a0);
+                M2[q] = fma(t22, a2, fma(t21, a1, t20 * a0));
+                M3[q] = fma(t33, a3, fma(t32, a2, fma(t31, a1, t30 * a0)));
+            }
+            const double li0 = Lc[buf][i][0], li1 = Lc[buf][i][1], li2 = Lc[buf][i][2], li3 = Lc[buf][i][3];   // own row of the L column block
+            if (g > G) {                                        // trailing entries: a_ic -= sum_k l_ik l_ck   (only i >= c is ever read)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 4 * g + q;
+                    e[q] = fma(-li3, Lc[buf][c][3], fma(-li2, Lc[buf][c][2], fma(-li1, Lc[buf][c][1], fma(-li0, Lc[buf][c][0], e[q]))));
+                }
+            }
+            if ((i >> 2) == G) {                                // these rows of L11^-1 are final
+                const int r = i & 3;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mi[q] = (r == 0) ? M0[q] : ((r == 1) ? M1[q] : ((r == 2) ? M2[q] : M3[q]));
+            } else if ((i >> 2) > G) {                          // R[i,:] -= sum_k l_ik M[k,:]
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mi[q] = fma(-li3, M3[q], fma(-li2, M2[q], fma(-li1, M1[q], fma(-li0, M0[q], mi[q]))));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 4 * g + q;
+            if (c <= i) W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = e[q];
+            Li[i][c] = (c <= i) ? mi[q] : 0.0;
+        }
+        if (bad && lane == 0) failed = 1;
+    };
+    // rows r0 .. r0+15 of the panel below the diagonal block: L21 tile = A21 tile * L11^-T on the matrix cores
+    auto panel_tile = [&](int j0, int r0) {
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double av = W[(size_t)(r0 + li) + (size_t)(j0 + kk * 4 + lk) * ldw];
+            const double bv = Li[li][kk * 4 + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);       // acc[r] = sum_k Linv[lk+4r][k] A21[r0+li][k]
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                           // every lane has read the tile: overwrite in place
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[(size_t)(r0 + li) + (size_t)(j0 + lk + 4 * r) * ldw] = acc[r];
+    };
+    auto trail_pair = [&](int j0, int t1, int q) {
+        int ta = 0, qq = q;
+        while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
+        const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int col = j0 + kk * 4 + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(size_t)(c0 + li) + (size_t)col * ldw], W[(size_t)(r0 + li) + (size_t)col * ldw], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r0 + li, c = c0 + lk + 4 * r;
+            if (i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
+        }
+    };
+    if (wv == 0) factor_diag_inv(0);
+    __syncthreads();
+    for (int j0 = 0; j0 < m; j0 += kNB) {
+        if (failed) break;
+        const int i1 = j0 + kNB, ntile = (m - i1) / 16, t1 = i1 / 16;
+        for (int t = wv; t < ntile; t += NW) panel_tile(j0, i1 + 16 * t);
+        __syncthreads();
+        if (ntile > 0) {
+            const int npair = ntile * (ntile + 1) / 2;
+            if (wv == 0) { trail_pair(j0, t1, 0); factor_diag_inv(i1); }         // look-ahead: next diagonal block while the others update
+            else for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q);
+        }
+        __syncthreads();
+    }
+    if (failed) {
+        if (tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+        return;
+    }
+    for (int j = wv; j < n; j += NW)
+        for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
+}
+
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s) {
     const int npad = (n + kNB - 1) / kNB * kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
         static std::atomic<unsigned long long> seen{0};
-        ensure_dyn_lds((const void*)k_potrf<true, 512>, 150 * 1024, seen);
-        hipLaunchKernelGGL((k_potrf<true, 512>), dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
+        ensure_dyn_lds((const void*)k_potrf_lds, 150 * 1024, seen);
+        hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
         const size_t strip = ((size_t)n * (kNB + 1) + kNB * (kNB + 1)) * sizeof(double);     // panel strip + diagonal block
         static std::atomic<unsigned long long> seen2{0};
