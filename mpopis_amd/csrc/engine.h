@@ -151,6 +151,9 @@ void launch_alias_sample(const double* accept, const int32_t* alias, const int32
 constexpr size_t kInvsqrtPadDoubles = 512;
 size_t invsqrt_workspace_doubles(int B, int n);
 int invsqrt_max_n();
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s);
+void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
+                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
                         double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);
 void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, int cs, int B, hipStream_t s);

@@ -98,6 +98,15 @@ int mpopis_handle::ais_update(int n, bool injected) {
         return MPOPIS_OK;
     }
     if (pol == MPOPIS_POL_CEMPPI || pol == MPOPIS_POL_CMAMPPI) {
+        const bool side = side_free && pol == MPOPIS_POL_CMAMPPI;
+        if (side) {
+            // tr(Σ^-1) = σ² ||L^-1||_F² needs only L = chol(σ²Σ): a latency-bound kernel of a few workgroups, run beside the equally
+            // latency-bound sort / elite mean on the free second stream (beside the rollout it cost the rollout more than it saved)
+            (void)hipEventRecord(ev_fork, stream);
+            (void)hipStreamWaitEvent(xstream[0], ev_fork, 0);
+            launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, xstream[0]);
+            (void)hipEventRecord(ev_join[0], xstream[0]);
+        }
         time_begin(5);
         launch_sortperm(d_cost, d_order, B, K, d_active, stream);                             // :455 / :563
         launch_elite_break(d_cost, d_order, B, K, m_elite, d_active, stream);                 // :458-461 / :566-569
@@ -126,7 +135,9 @@ int mpopis_handle::ais_update(int n, bool injected) {
         launch_gather_mean_strided(d_E, d_order, d_cma_ws, dw, (size_t)3 * cs, B, cs, K, m_elite, d_active, stream);   // :573-576
         // C = Σ^-0.5 (:580) is only consumed as C*δw (:581) and ||C||_F (:593): neither needs the matrix.  d_L = chol(σ²Σ) is the
         // factor this iteration sampled from (same Σ: the update :598 comes after), so tr(Σ^-1) = σ² ||L^-1||_F²
-        launch_invsqrt_vec(d_Sig, d_L, (size_t)cs * cs, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream);
+        if (side) (void)hipStreamWaitEvent(stream, ev_join[0], 0);
+        else launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, stream);
+        launch_lanczos_invsqrt(d_Sig, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream);
         launch_cma_paths(d_Cdw, d_fro, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
         launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);
         time_end();

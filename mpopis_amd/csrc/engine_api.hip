@@ -606,7 +606,9 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     const long long rollout_waves = (long long)B0 * ((K + 63) / 64) * std::max(1, env.ncars);
     const int np = (split_auto && rollout_waves < 2048) ? 1 : std::min(nsplit, B0);
     if (np < 2) {
+        side_free = (xstream[0] != nullptr);
         const int rc = step_enqueue_view(injected, nullptr, nullptr);
+        side_free = false;
         mpc_step += 1;
         if (!rc && !launch_err.empty()) { err = launch_err; launch_err.clear(); return MPOPIS_ERR_HIP; }
         return rc;

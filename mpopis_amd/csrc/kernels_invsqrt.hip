@@ -355,18 +355,31 @@ int invsqrt_max_n() {
 
 // y = A^-1/2 b and fro = tr(A^-1) per slot, from A (n x n, SPD) and the Cholesky factor L of scale*A (scale: per-slot, nullable).
 // A must stay readable for kInvsqrtPadDoubles doubles behind its last slot (the mat-vec reads whole 64-row chunks).
-void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
-                        double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
+// part[b][nb] = per-block-column partial sums of ||L^-1||_F^2 (only L is read: may run on another stream beside the sort / elite mean)
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s) {
     const int nb = (n + kTB - 1) / kTB;
     const size_t lds1 = ((size_t)2 * nb * 256 + kInvWaves * 256 + kInvWaves) * sizeof(double);
-    static std::atomic<unsigned long long> seen1{0}, seen2{0};
+    static std::atomic<unsigned long long> seen1{0};
     ensure_dyn_lds((const void*)k_trtri_fro, 150 * 1024, seen1);
     hipLaunchKernelGGL(k_trtri_fro, dim3(nb, B), dim3(kInvThreads), lds1, s, L, Lstride, n, nb, part, active);
+}
+
+// y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound)
+void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
+                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
+    const int nb = (n + kTB - 1) / kTB;
+    static std::atomic<unsigned long long> seen2{0};
     const size_t fixed = (size_t)(kLanWaves + 6) * n + 1 + kLanWaves + 4 + 2 * kLanPivLds * 64;        // doubles
     const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);            // basis vectors that fit next to it
     const size_t lds2 = (fixed + (size_t)nvl * n) * sizeof(double);
     ensure_dyn_lds((const void*)k_lanczos_invsqrt, 150 * 1024, seen2);
     hipLaunchKernelGGL(k_lanczos_invsqrt, dim3(B), dim3(kLanThreads), lds2, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl, status, active);
+}
+
+void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
+                        double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
+    launch_trtri_fro(L, Lstride, part, B, n, active, s);
+    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s);
 }
 
 }  // namespace mpopis

@@ -11,15 +11,12 @@ namespace mpopis {
 constexpr int kNB = 16;
 
 // ---------------------------------------------------------------------------------------------
-// Blocked right-looking Cholesky, one workgroup (4 waves) per matrix, panel width 16:
-//   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row; v_readlane broadcasts,
-//       rsqrt + multiply instead of sqrt + divide),
-//   (2) one thread per row solves the panel below it (forward substitution against L11, reciprocal
-//       diagonal),
-//   (3) the rank-16 trailing update runs on the matrix cores: per 16x16 tile 4 x v_mfma_f64_16x16x4
-//       (A = panel rows of the tile row, B = panel rows of the tile column), read-modify-write.
-// The working copy lives in LDS when it fits (npad^2*8 <= 150 KiB, i.e. cs <= 128: all 1-car configs),
-// otherwise in the output buffer in global memory (L2 resident; cs = 300 for 3 cars).
+// Blocked right-looking Cholesky, one workgroup per matrix, panel width 16 (k_potrf_lds: working copy in LDS, cs <= 128, all
+// 1-car configs; k_potrf_global: working copy = the output buffer, L2 resident, cs = 300 for 3 cars).  Per panel:
+//   (1) one wave factors the 16x16 diagonal block AND inverts it (diag16_factor_inv: 4x4 sub-blocks, one LDS exchange each),
+//   (2) the panel below it is L21 = A21 * L11^-T on the matrix cores (v_mfma_f64_16x16x4, one 16-row tile per wave),
+//   (3) the rank-16 trailing update runs on the matrix cores too, 4 MFMAs per 16x16 tile, read-modify-write; the wave that owns
+//       the next diagonal block updates it first and factors it while the others finish the update (look-ahead).
 // scale[b] (nullable) multiplies A first (CMA: MvNormal(σ²Σ), :551).  On a non-positive pivot
 // status[b] = MPOPIS_ERR_NOT_PD and active[b] = 0 (the reference throws PosDefException).
 // ---------------------------------------------------------------------------------------------
@@ -31,244 +28,23 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {     // src is 
     return __hiloint2double(hi, lo);
 }
 
-template <bool LDS, int NTHR>
-__global__ void __launch_bounds__(NTHR) k_potrf(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
-                                               int n, int npad, const double* scale, int* status, int* active) {
-    MPOPIS_HI_PRIO();
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int failed;
-    __shared__ double rdiag[kNB];
-    const int b = blockIdx.x;
-    if (active && !active[b]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double* Ab = A + (size_t)b * Astride;
-    double* Lb = Lout + (size_t)b * n * n;
-    const double sc = scale ? scale[b] : 1.0;
-    // working matrix W (ld = ldw): the LDS copy is padded to a multiple of 16 with an identity tail
-    double* W; int ldw, m;
-    if (LDS) { W = smem; ldw = npad; m = npad; } else { W = Lb; ldw = n; m = n; }
-    // global-memory variant: the solved panel strip P[m][17] (both operands of the trailing update) and the current diagonal
-    // block D11[16][17] (read by every row of the panel solve) live in LDS; only the trailing read-modify-write goes to L2
-    constexpr int kPS = kNB + 1;
-    double* P = LDS ? nullptr : smem;
-    double* D11 = LDS ? nullptr : smem + (size_t)n * kPS;
-    if (tid == 0) failed = 0;
-    // copy in the lower triangle only (the upper triangle of W is never consumed): columns c and m-1-c together hold m+1
-    // entries, so the triangle is the (m/2) x (m+1) rectangle e -> (c, t); batches of 8 unconditional (clamped) loads in
-    // flight per thread, select afterwards.  (m even: npad is a multiple of 16; the global-memory variant keeps m = n.)
-    if (LDS) {
-        constexpr int NW = NTHR / 64;
-        // column pair c (columns c and m-1-c) holds m+1 triangle entries t: wave -> pairs, lane -> t (no integer divisions);
-        // 4 pairs x 2 lane chunks = 8 unconditional (clamped) loads in flight per thread, select afterwards
-        const int npairs2 = m / 2, tchunks = (m + 1 + 63) / 64;
-        for (int c0 = wv * 4; c0 < npairs2; c0 += NW * 4) {
-            for (int tc = 0; tc < tchunks; tc += 2) {
-                double av[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = min(c0 + (u >> 1), npairs2 - 1), t = min((tc + (u & 1)) * 64 + lane, m);
-                    const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                    av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + (u >> 1), t = (tc + (u & 1)) * 64 + lane;
-                    if (c < npairs2 && t <= m && tc + (u & 1) < tchunks) {
-                        const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                        W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
-                    }
-                }
-            }
-        }
-    } else {
-        for (int e0 = tid; e0 < m * m; e0 += NTHR * 8) {
-            double av[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = min(e0 + u * NTHR, m * m - 1), i = e % m, j = e / m;
-                av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * NTHR;
-                if (e < m * m) {
-                    const int i = e % m, j = e / m;
-                    W[(size_t)i + (size_t)j * ldw] = (i >= j) ? sc * av[u] : 0.0;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    const int li = lane & 15, lk = lane >> 4;
-    constexpr int NW = NTHR / 64;
-    // (1) diagonal block, one wave, lane = row (rows/cols >= nb behave as identity)
-    auto factor_diag = [&](int j0, int nb) {
-        double d[kNB];
-        const bool rowok = lane < nb;
-#pragma unroll
-        for (int c = 0; c < kNB; ++c) d[c] = (rowok && c < nb) ? W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] : ((lane == c) ? 1.0 : 0.0);
-        bool bad = false;
-#pragma unroll
-        for (int jj = 0; jj < kNB; ++jj) {
-            const double piv = bcast_lane(d[jj], jj);
-            if (!(piv > 0.0)) bad = true;
-            double rs = __builtin_amdgcn_rsq(piv);              // v_rsq_f64 seed + 2 Newton steps (full precision)
-            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-            const double ljj = piv * rs;                        // sqrt(piv)
-            if (lane == jj) { d[jj] = ljj; rdiag[jj] = rs; } else if (lane > jj) d[jj] = d[jj] * rs;
-#pragma unroll
-            for (int c = jj + 1; c < kNB; ++c) {
-                const double lcj = bcast_lane(d[jj], c);
-                if (lane >= c) d[c] = fma(-d[jj], lcj, d[c]);
-            }
-        }
-        if (rowok) {
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) if (c < nb && c <= lane) {
-                W[(size_t)(j0 + lane) + (size_t)(j0 + c) * ldw] = d[c];
-                if (!LDS) D11[lane * kPS + c] = d[c];
-            }
-        }
-        if (bad && lane == 0) failed = 1;
-    };
-    // (3) one 16x16 tile of the rank-16 trailing update on the matrix cores: pair q -> tile (t1 + ta, t1 + tb), ta >= tb
-    auto trail_pair = [&](int j0, int t1, int q) {
-        int ta = 0, qq = q;
-        while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
-        const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
-        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int ra = r0 + li, rb = c0 + li, col = j0 + kk * 4 + lk;
-            const double av = (ra < m) ? (LDS ? W[(size_t)ra + (size_t)col * ldw] : P[(size_t)ra * kPS + kk * 4 + lk]) : 0.0;
-            const double bv = (rb < m) ? (LDS ? W[(size_t)rb + (size_t)col * ldw] : P[(size_t)rb * kPS + kk * 4 + lk]) : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = r0 + li, c = c0 + lk + 4 * r;                               // D'[c - c0][i - r0]
-            if (i < m && c < m && i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
-        }
-    };
-    if (wv == 0) factor_diag(0, min(kNB, m));
-    __syncthreads();
-    for (int j0 = 0; j0 < m; j0 += kNB) {
-        if (failed) break;
-        const int nb = min(kNB, m - j0);
-        const int i1 = j0 + nb;              // first row below the panel
-        // (2) panel solve: row i of L21 = A21[i,:] * L11^-T
-        for (int i = i1 + tid; i < m; i += NTHR) {
-            double x[kNB];
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) x[c] = (c < nb) ? W[(size_t)i + (size_t)(j0 + c) * ldw] : 0.0;
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) {
-                if (c < nb) {
-                    double v = x[c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) v = fma(-x[k], LDS ? W[(size_t)(j0 + c) + (size_t)(j0 + k) * ldw] : D11[c * kPS + k], v);
-                    x[c] = v * rdiag[c];
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < kNB; ++c) if (c < nb) {
-                W[(size_t)i + (size_t)(j0 + c) * ldw] = x[c];
-                if (!LDS) P[(size_t)i * kPS + c] = x[c];
-            }
-        }
-        __syncthreads();
-        // (3) trailing update with one panel of look-ahead: wave 0 updates the next diagonal tile first and factors it
-        // right away, while the other waves update the remaining tiles (rows/cols beyond the panel)
-        const int t1 = i1 / 16;                                  // i1 is a multiple of 16 except after the last (partial) panel
-        const int ntile = (m + 15) / 16 - t1;
-        if (nb == kNB && ntile > 0) {
-            const int npair = ntile * (ntile + 1) / 2;
-            if (wv == 0) {
-                trail_pair(j0, t1, 0);
-                if (!LDS) __threadfence_block();
-                factor_diag(i1, min(kNB, m - i1));
-                if (NW == 1) for (int q = 1; q < npair; ++q) trail_pair(j0, t1, q);
-            } else {
-                for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q);
-            }
-        }
-        __syncthreads();
-    }
-    if (failed) {
-        if (tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
-        return;
-    }
-    if (LDS) {
-        for (int j = wv; j < n; j += NTHR / 64)
-            for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// LDS-resident Cholesky for n <= 128 (every 1-car configuration), one workgroup of 8 waves per matrix.  Same blocked
-// right-looking scheme as k_potrf, but the two serial pieces of a panel -- which bound it: 7 panels x (diagonal block 3.9 us +
-// panel solve 2.9 us) of 63 us at n = 100 -- are reorganised:
-//   * diagonal 16x16 block: lane = (row i, column group g), 4 entries per lane, processed as 4x4 sub-blocks with one LDS
-//     exchange per sub-block column (instead of 15 v_readlane broadcasts per pivot), and the SAME loop carries a second 16x16
-//     block along that ends up as L11^-1 (right-looking forward substitution on the identity);
-//   * panel solve L21 = A21 L11^-T becomes one 16x16x16 product per row tile on the matrix cores (B operand = L11^-1),
-//     instead of a 136-term dependent substitution per row fed by LDS reads.
-// Using the explicit inverse of the (well-conditioned) 16x16 diagonal block costs ~cond(L11) eps in L21, far inside the
-// parity budget (|L L' - A| stays at 1e-16 |A| in tools/kbench_linalg).
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
-                                                   int n, int npad, const double* scale, int* status, int* active) {
-    MPOPIS_HI_PRIO();
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int failed;
-    __shared__ double Lc[2][kNB][5], Rr[2][4][kNB + 1], Li[kNB][kNB + 1];
-    constexpr int NTHR = 512, NW = NTHR / 64;
-    const int b = blockIdx.x;
-    if (active && !active[b]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double* Ab = A + (size_t)b * Astride;
-    double* Lb = Lout + (size_t)b * n * n;
-    const double sc = scale ? scale[b] : 1.0;
-    double* W = smem;                                  // [npad][npad] column-major, identity tail beyond n
-    const int ldw = npad, m = npad;
-    if (tid == 0) failed = 0;
-    {   // copy in the lower triangle only (see k_potrf): column pair c (columns c and m-1-c) holds m+1 triangle entries
-        const int npairs2 = m / 2, tchunks = (m + 1 + 63) / 64;
-        for (int c0 = wv * 4; c0 < npairs2; c0 += NW * 4) {
-            for (int tc = 0; tc < tchunks; tc += 2) {
-                double av[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = min(c0 + (u >> 1), npairs2 - 1), t = min((tc + (u & 1)) * 64 + lane, m);
-                    const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                    av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int c = c0 + (u >> 1), t = (tc + (u & 1)) * 64 + lane;
-                    if (c < npairs2 && t <= m && tc + (u & 1) < tchunks) {
-                        const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
-                        W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const int li = lane & 15, lk = lane >> 4;
-    // diagonal block at j0: L11 -> W, L11^-1 -> Li.  One wave; lane = (row i = li, column group g = lk), entries of columns 4g .. 4g+3.
-    // Processed as a 4 x 4 grid of 4x4 sub-blocks, ONE LDS exchange per sub-block column G (a lone wave issues a dependent
-    // instruction only every ~8 cycles and an LDS round trip costs ~100+: the per-pivot version of this loop took 900 cycles per
-    // pivot).  Per G: every lane gathers the diagonal 4x4 sub-block (v_readlane), factors and inverts it redundantly in registers,
-    // the lanes of column group G turn their row into L (rows below: x T', T = L4^-1), the L column block and the R rows of
-    // group G go through LDS, and every lane updates its trailing entries and its rows of R = (rows of L11^-1 in the making).
-    auto factor_diag_inv = [&](int j0) {
-        const int i = li, g = lk;
+// 16x16 diagonal block: Cholesky factor (written through `store`) and its inverse (into sh.Li), by ONE wave; lane = (row i, column
+// group g), entries of columns 4g .. 4g+3, loaded through `load(i, c)` (identity beyond the matrix edge).  Processed as a 4 x 4
+// grid of 4x4 sub-blocks with ONE LDS exchange per sub-block column G (a lone wave issues a dependent instruction only every ~8
+// cycles and an LDS round trip costs ~100+: a per-pivot formulation took 900 cycles per pivot).  Per G: every lane gathers the
+// diagonal 4x4 sub-block (v_readlane), factors and inverts it redundantly in registers, the lanes of column group G turn their
+// row into L (rows below: x T', T = L4^-1), the L column block and the R rows of group G go through LDS, and every lane updates its
+// trailing entries and its rows of R (= the rows of L11^-1 in the making: right-looking forward substitution on the identity).
+// Returns true on a non-positive pivot.
+struct DiagScratch { double Lc[2][kNB][5], Rr[2][4][kNB + 1], Li[kNB][kNB + 1]; };
+template <class LoadF, class StoreF>
+__device__ __forceinline__ bool diag16_factor_inv(int lane, LoadF load, StoreF store, DiagScratch& sh) {
+    auto& Lc = sh.Lc; auto& Rr = sh.Rr; auto& Li = sh.Li;
+    {
+        const int i = lane & 15, g = lane >> 4;
         double e[4], mi[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { e[q] = W[(size_t)(j0 + i) + (size_t)(j0 + 4 * g + q) * ldw]; mi[q] = (i == 4 * g + q) ? 1.0 : 0.0; }
+        for (int q = 0; q < 4; ++q) { e[q] = load(i, 4 * g + q); mi[q] = (i == 4 * g + q) ? 1.0 : 0.0; }
         bool bad = false;
         auto rsqrt_full = [&](double piv) {                     // v_rsq_f64 seed + 2 Newton steps (full precision)
             if (!(piv > 0.0)) bad = true;
@@ -351,9 +127,69 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 4 * g + q;
-            if (c <= i) W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = e[q];
+            if (c <= i) store(i, c, e[q]);
             Li[i][c] = (c <= i) ? mi[q] : 0.0;
         }
+        return bad;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-resident Cholesky for n <= 128 (every 1-car configuration), one workgroup of 8 waves per matrix.  Same blocked
+// right-looking scheme as k_potrf, but the two serial pieces of a panel -- which bound it: 7 panels x (diagonal block 3.9 us +
+// panel solve 2.9 us) of 63 us at n = 100 -- are reorganised:
+//   * diagonal 16x16 block: lane = (row i, column group g), 4 entries per lane, processed as 4x4 sub-blocks with one LDS
+//     exchange per sub-block column (instead of 15 v_readlane broadcasts per pivot), and the SAME loop carries a second 16x16
+//     block along that ends up as L11^-1 (right-looking forward substitution on the identity);
+//   * panel solve L21 = A21 L11^-T becomes one 16x16x16 product per row tile on the matrix cores (B operand = L11^-1),
+//     instead of a 136-term dependent substitution per row fed by LDS reads.
+// Using the explicit inverse of the (well-conditioned) 16x16 diagonal block costs ~cond(L11) eps in L21, far inside the
+// parity budget (|L L' - A| stays at 1e-16 |A| in tools/kbench_linalg).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
+                                                   int n, int npad, const double* scale, int* status, int* active) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int failed;
+    __shared__ DiagScratch dsh;
+    constexpr int NTHR = 512, NW = NTHR / 64;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* Ab = A + (size_t)b * Astride;
+    double* Lb = Lout + (size_t)b * n * n;
+    const double sc = scale ? scale[b] : 1.0;
+    double* W = smem;                                  // [npad][npad] column-major, identity tail beyond n
+    const int ldw = npad, m = npad;
+    if (tid == 0) failed = 0;
+    {   // copy in the lower triangle only (see k_potrf): column pair c (columns c and m-1-c) holds m+1 triangle entries
+        const int npairs2 = m / 2, tchunks = (m + 1 + 63) / 64;
+        for (int c0 = wv * 4; c0 < npairs2; c0 += NW * 4) {
+            for (int tc = 0; tc < tchunks; tc += 2) {
+                double av[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = min(c0 + (u >> 1), npairs2 - 1), t = min((tc + (u & 1)) * 64 + lane, m);
+                    const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                    av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(j, n - 1) * n];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + (u >> 1), t = (tc + (u & 1)) * 64 + lane;
+                    if (c < npairs2 && t <= m && tc + (u & 1) < tchunks) {
+                        const int j = (t < m - c) ? c : m - 1 - c, i = (t < m - c) ? c + t : m - 1 - c + (t - (m - c));
+                        W[(size_t)i + (size_t)j * ldw] = (i < n && j < n) ? sc * av[u] : ((i == j) ? 1.0 : 0.0);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    auto factor_diag_inv = [&](int j0) {
+        const bool bad = diag16_factor_inv(lane,
+            [&](int i, int c) { return W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw]; },
+            [&](int i, int c, double v) { W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
         if (bad && lane == 0) failed = 1;
     };
     // rows r0 .. r0+15 of the panel below the diagonal block: L21 tile = A21 tile * L11^-T on the matrix cores
@@ -362,7 +198,7 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const double av = W[(size_t)(r0 + li) + (size_t)(j0 + kk * 4 + lk) * ldw];
-            const double bv = Li[li][kk * 4 + lk];
+            const double bv = dsh.Li[li][kk * 4 + lk];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);       // acc[r] = sum_k Linv[lk+4r][k] A21[r0+li][k]
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -409,6 +245,96 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
         for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
 }
 
+// Global-memory variant for matrices that do not fit in LDS (cs = 300: three cars), one workgroup of 16 waves: the working
+// matrix is the output buffer (L2 resident); the solved panel strip P[m][17] -- both operands of the rank-16 trailing update --
+// lives in LDS, only the trailing read-modify-write goes to L2.  Diagonal blocks and panel solves as in k_potrf_lds.
+__global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
+                                                       int n, const double* scale, int* status, int* active) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int failed;
+    __shared__ DiagScratch dsh;
+    constexpr int NTHR = 1024, NW = NTHR / 64, kPS = kNB + 1;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const double* Ab = A + (size_t)b * Astride;
+    double* W = Lout + (size_t)b * n * n;
+    const double sc = scale ? scale[b] : 1.0;
+    const int ldw = n, m = n;
+    double* P = smem;                                   // [m][17] solved panel strip
+    if (tid == 0) failed = 0;
+    for (int e0 = tid; e0 < m * m; e0 += NTHR * 8) {    // W = lower(sc * A), zeros above the diagonal
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = min(e0 + u * NTHR, m * m - 1); av[u] = Ab[(size_t)(e % m) + (size_t)(e / m) * n]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * NTHR;
+            if (e < m * m) { const int i = e % m, j = e / m; W[(size_t)i + (size_t)j * ldw] = (i >= j) ? sc * av[u] : 0.0; }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    auto factor_diag_inv = [&](int j0) {
+        const bool bad = diag16_factor_inv(lane,
+            [&](int i, int c) { return (j0 + i < m && j0 + c < m) ? W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] : ((i == c) ? 1.0 : 0.0); },
+            [&](int i, int c, double v) { if (j0 + i < m && j0 + c < m) W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
+        if (bad && lane == 0) failed = 1;
+    };
+    auto panel_tile = [&](int j0, int r0) {              // L21 tile = A21 tile * L11^-T on the matrix cores; result to W (L2) and P (LDS)
+        const int ra = r0 + li;
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+        double av[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { const int col = j0 + kk * 4 + lk; av[kk] = (ra < m && col < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dsh.Li[li][kk * 4 + lk], av[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = lk + 4 * r;
+            if (ra < m) { P[(size_t)ra * kPS + c] = acc[r]; if (j0 + c < m) W[(size_t)ra + (size_t)(j0 + c) * ldw] = acc[r]; }
+        }
+    };
+    auto trail_pair = [&](int j0, int t1, int q) {       // one 16x16 tile of the rank-16 trailing update: pair q -> tile (t1 + ta, t1 + tb), ta >= tb
+        int ta = 0, qq = q;
+        while (qq >= ta + 1) { qq -= ta + 1; ++ta; }
+        const int r0 = (t1 + ta) * 16, c0 = (t1 + qq) * 16;
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ra = r0 + li, rb = c0 + li;
+            const double av = (ra < m) ? P[(size_t)ra * kPS + kk * 4 + lk] : 0.0;
+            const double bv = (rb < m) ? P[(size_t)rb * kPS + kk * 4 + lk] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // transposed tile: lanes run along i
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r0 + li, c = c0 + lk + 4 * r;
+            if (i < m && c < m && i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
+        }
+    };
+    if (wv == 0) factor_diag_inv(0);
+    __threadfence_block();
+    __syncthreads();
+    for (int j0 = 0; j0 < m; j0 += kNB) {
+        if (failed) break;
+        const int i1 = j0 + kNB;                          // first row below the panel (>= m after the last, possibly partial, panel)
+        const int ntile = (i1 < m) ? (m - i1 + 15) / 16 : 0, t1 = i1 / 16;
+        for (int t = wv; t < ntile; t += NW) panel_tile(j0, i1 + 16 * t);
+        __threadfence_block();
+        __syncthreads();
+        if (ntile > 0) {
+            const int npair = ntile * (ntile + 1) / 2;
+            if (wv == 0) { trail_pair(j0, t1, 0); __threadfence_block(); factor_diag_inv(i1); }   // look-ahead: next diagonal block first
+            else for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (failed && tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+}
+
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s) {
     const int npad = (n + kNB - 1) / kNB * kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
@@ -417,10 +343,10 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
         ensure_dyn_lds((const void*)k_potrf_lds, 150 * 1024, seen);
         hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
     } else {
-        const size_t strip = ((size_t)n * (kNB + 1) + kNB * (kNB + 1)) * sizeof(double);     // panel strip + diagonal block
+        const size_t strip = (size_t)n * (kNB + 1) * sizeof(double);                         // panel strip
         static std::atomic<unsigned long long> seen2{0};
-        ensure_dyn_lds((const void*)k_potrf<false, 1024>, 150 * 1024, seen2);
-        hipLaunchKernelGGL((k_potrf<false, 1024>), dim3(B), dim3(1024), strip, s, A, Astride, L, n, n, scale, status, active);
+        ensure_dyn_lds((const void*)k_potrf_global, 150 * 1024, seen2);
+        hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active);
     }
 }
 
