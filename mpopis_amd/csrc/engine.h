@@ -116,7 +116,9 @@ void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const u
 
 
 // kernels_linalg.hip
-void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s);
+size_t potrf_coop_flag_words(int B, int n);
+void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
+                  unsigned long long* coop_flags = nullptr, unsigned long long* coop_epoch = nullptr);
 void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
 // kernels_mfma.hip

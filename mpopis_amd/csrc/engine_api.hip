@@ -151,6 +151,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
     rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn + kInvsqrtPadDoubles); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
     rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
+    rc |= dalloc(h, &h->d_coop_flags, potrf_coop_flag_words(B, cs));
     rc |= dalloc(h, &h->d_Z, (size_t)B * cs * K); rc |= dalloc(h, &h->d_E, (size_t)B * cs * K);
     rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);
     rc |= dalloc(h, &h->d_wn, (size_t)B * cs); rc |= dalloc(h, &h->d_mu, (size_t)B * cs); rc |= dalloc(h, &h->d_gvec, (size_t)B * cs);
@@ -332,7 +333,7 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     HIPCHK(h, hipMemcpyAsync(h->d_dscale0, ds.data(), sizeof(double) * cs, hipMemcpyHostToDevice, h->stream));
     // factor once: L0 (shared by all slots; the reference refactors the same Σ every call, :307)
     fill_i32(h->d_status, 0, h->B, h->stream);
-    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream);
+    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->d_coop_flags, &h->coop_epoch);
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->h_status[0] != 0) { h->err = "PosDefException: Sigma is not positive definite"; return MPOPIS_ERR_NOT_PD; }
@@ -591,6 +592,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
     mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
     mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_fro, 1); mv(d_lan_m, 1);
+    mv(d_coop_flags, (ptrdiff_t)potrf_coop_flag_words(1, cs));
     mv(alive_gate, 1);
 }
 
@@ -655,7 +657,8 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         if (sigma_fixed || (n == 1 && pol != MPOPIS_POL_CMAMPPI)) { Lp = d_L0; Lstride = 0; }
         else {
             time_begin(2);
-            launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream);
+            launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream,
+                         d_coop_flags, &coop_epoch);
             time_end();
             Lp = d_L; Lstride = nn;
         }

@@ -5,146 +5,27 @@
 //   mean(elite, dims=2) / mean of resampled columns / CMA δw (gather + mean)  :465,:807,:573-576
 // (the covariance contractions live in kernels_mfma.hip)
 #include "engine.h"
+#include "linalg_diag.h"
 
 namespace mpopis {
-
-constexpr int kNB = 16;
 
 // ---------------------------------------------------------------------------------------------
 // Blocked right-looking Cholesky, one workgroup per matrix, panel width 16 (k_potrf_lds: working copy in LDS, cs <= 128, all
 // 1-car configs; k_potrf_global: working copy = the output buffer, L2 resident, cs = 300 for 3 cars).  Per panel:
-//   (1) one wave factors the 16x16 diagonal block AND inverts it (diag16_factor_inv: 4x4 sub-blocks, one LDS exchange each),
-//   (2) the panel below it is L21 = A21 * L11^-T on the matrix cores (v_mfma_f64_16x16x4, one 16-row tile per wave),
+//   (1) one wave factors the 16x16 diagonal block (linalg_diag.h, diag16_factor: 4x4 sub-blocks, one LDS exchange each),
+//   (2) the panel below it is L21 = A21 * L11^-T as a blocked forward substitution on the matrix cores (panel_solve_tile:
+//       7 x v_mfma_f64_16x16x4 per 16-row tile against the 4x4 diagonal inverses and the sub-diagonal blocks of L11),
 //   (3) the rank-16 trailing update runs on the matrix cores too, 4 MFMAs per 16x16 tile, read-modify-write; the wave that owns
 //       the next diagonal block updates it first and factors it while the others finish the update (look-ahead).
 // scale[b] (nullable) multiplies A first (CMA: MvNormal(σ²Σ), :551).  On a non-positive pivot
 // status[b] = MPOPIS_ERR_NOT_PD and active[b] = 0 (the reference throws PosDefException).
 // ---------------------------------------------------------------------------------------------
-typedef double v4f64_l __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double bcast_lane(double v, int src) {     // src is a compile-time constant after unrolling
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
-// 16x16 diagonal block: Cholesky factor (written through `store`) and its inverse (into sh.Li), by ONE wave; lane = (row i, column
-// group g), entries of columns 4g .. 4g+3, loaded through `load(i, c)` (identity beyond the matrix edge).  Processed as a 4 x 4
-// grid of 4x4 sub-blocks with ONE LDS exchange per sub-block column G (a lone wave issues a dependent instruction only every ~8
-// cycles and an LDS round trip costs ~100+: a per-pivot formulation took 900 cycles per pivot).  Per G: every lane gathers the
-// diagonal 4x4 sub-block (v_readlane), factors and inverts it redundantly in registers, the lanes of column group G turn their
-// row into L (rows below: x T', T = L4^-1), the L column block and the R rows of group G go through LDS, and every lane updates its
-// trailing entries and its rows of R (= the rows of L11^-1 in the making: right-looking forward substitution on the identity).
-// Returns true on a non-positive pivot.
-struct DiagScratch { double Lc[2][kNB][5], Rr[2][4][kNB + 1], Li[kNB][kNB + 1]; };
-template <class LoadF, class StoreF>
-__device__ __forceinline__ bool diag16_factor_inv(int lane, LoadF load, StoreF store, DiagScratch& sh) {
-    auto& Lc = sh.Lc; auto& Rr = sh.Rr; auto& Li = sh.Li;
-    {
-        const int i = lane & 15, g = lane >> 4;
-        double e[4], mi[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { e[q] = load(i, 4 * g + q); mi[q] = (i == 4 * g + q) ? 1.0 : 0.0; }
-        bool bad = false;
-        auto rsqrt_full = [&](double piv) {                     // v_rsq_f64 seed + 2 Newton steps (full precision)
-            if (!(piv > 0.0)) bad = true;
-            double rs = __builtin_amdgcn_rsq(piv);
-            rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-            return rs * fma(-0.5 * piv * rs, rs, 1.5);
-        };
-#pragma unroll
-        for (int G = 0; G < 4; ++G) {
-            const int buf = G & 1;
-            // (a) the 4x4 diagonal sub-block (lower part), from lanes (4G + r, G)
-            const double s00 = bcast_lane(e[0], 4 * G + 0 + 16 * G);
-            const double s10 = bcast_lane(e[0], 4 * G + 1 + 16 * G), s11 = bcast_lane(e[1], 4 * G + 1 + 16 * G);
-            const double s20 = bcast_lane(e[0], 4 * G + 2 + 16 * G), s21 = bcast_lane(e[1], 4 * G + 2 + 16 * G), s22 = bcast_lane(e[2], 4 * G + 2 + 16 * G);
-            const double s30 = bcast_lane(e[0], 4 * G + 3 + 16 * G), s31 = bcast_lane(e[1], 4 * G + 3 + 16 * G), s32 = bcast_lane(e[2], 4 * G + 3 + 16 * G),
-                         s33 = bcast_lane(e[3], 4 * G + 3 + 16 * G);
-            // Cholesky of the sub-block and its inverse T (both lower triangular), in registers
-            const double r0 = rsqrt_full(s00), l00 = s00 * r0, l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
-            const double d1 = fma(-l10, l10, s11), r1 = rsqrt_full(d1), l11 = d1 * r1;
-            const double l21 = fma(-l20, l10, s21) * r1, l31 = fma(-l30, l10, s31) * r1;
-            const double d2 = fma(-l21, l21, fma(-l20, l20, s22)), r2 = rsqrt_full(d2), l22 = d2 * r2;
-            const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
-            const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33))), r3 = rsqrt_full(d3), l33 = d3 * r3;
-            const double t00 = r0, t11 = r1, t22 = r2, t33 = r3;
-            const double t10 = -(l10 * t00) * r1, t21 = -(l21 * t11) * r2, t32 = -(l32 * t22) * r3;
-            const double t20 = -fma(l21, t10, l20 * t00) * r2, t31 = -fma(l32, t21, l31 * t11) * r3;
-            const double t30 = -fma(l32, t20, fma(l31, t10, l30 * t00)) * r3;
-            // (b) column block G of L: the sub-block rows take L4, rows below x T' (x = the row's four entries), rows above 0
-            if (g == G) {
-                const int r = i - 4 * G;
-                double n0, n1, n2, n3;
-                if (r < 0) { n0 = n1 = n2 = n3 = 0.0; }
-                else if (r == 0) { n0 = l00; n1 = n2 = n3 = 0.0; }
-                else if (r == 1) { n0 = l10; n1 = l11; n2 = n3 = 0.0; }
-                else if (r == 2) { n0 = l20; n1 = l21; n2 = l22; n3 = 0.0; }
-                else if (r == 3) { n0 = l30; n1 = l31; n2 = l32; n3 = l33; }
-                else {
-                    n0 = e[0] * t00;
-                    n1 = fma(e[1], t11, e[0] * t10);
-                    n2 = fma(e[2], t22, fma(e[1], t21, e[0] * t20));
-                    n3 = fma(e[3], t33, fma(e[2], t32, fma(e[1], t31, e[0] * t30)));
-                }
-                e[0] = n0; e[1] = n1; e[2] = n2; e[3] = n3;
-                Lc[buf][i][0] = n0; Lc[buf][i][1] = n1; Lc[buf][i][2] = n2; Lc[buf][i][3] = n3;
-            }
-            if ((i >> 2) == G) {                                // R rows of group G, all column groups
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Rr[buf][i & 3][4 * g + q] = mi[q];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // rows 4G..4G+3 of L11^-1 restricted to this lane's columns: M[k][q] = sum_{k' <= k} T[k][k'] R[4G+k'][4g+q]
-            double M0[4], M1[4], M2[4], M3[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double a0 = Rr[buf][0][4 * g + q], a1 = Rr[buf][1][4 * g + q], a2 = Rr[buf][2][4 * g + q], a3 = Rr[buf][3][4 * g + q];
-                M0[q] = t00 * a0;
-                M1[q] = fma(t11, a1, t10 * a0);
-                M2[q] = fma(t22, a2, fma(t21, a1, t20 * a0));
-                M3[q] = fma(t33, a3, fma(t32, a2, fma(t31, a1, t30 * a0)));
-            }
-            const double li0 = Lc[buf][i][0], li1 = Lc[buf][i][1], li2 = Lc[buf][i][2], li3 = Lc[buf][i][3];   // own row of the L column block
-            if (g > G) {                                        // trailing entries: a_ic -= sum_k l_ik l_ck   (only i >= c is ever read)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = 4 * g + q;
-                    e[q] = fma(-li3, Lc[buf][c][3], fma(-li2, Lc[buf][c][2], fma(-li1, Lc[buf][c][1], fma(-li0, Lc[buf][c][0], e[q]))));
-                }
-            }
-            if ((i >> 2) == G) {                                // these rows of L11^-1 are final
-                const int r = i & 3;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mi[q] = (r == 0) ? M0[q] : ((r == 1) ? M1[q] : ((r == 2) ? M2[q] : M3[q]));
-            } else if ((i >> 2) > G) {                          // R[i,:] -= sum_k l_ik M[k,:]
-#pragma unroll
-                for (int q = 0; q < 4; ++q) mi[q] = fma(-li3, M3[q], fma(-li2, M2[q], fma(-li1, M1[q], fma(-li0, M0[q], mi[q]))));
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = 4 * g + q;
-            if (c <= i) store(i, c, e[q]);
-            Li[i][c] = (c <= i) ? mi[q] : 0.0;
-        }
-        return bad;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// LDS-resident Cholesky for n <= 128 (every 1-car configuration), one workgroup of 8 waves per matrix.  Same blocked
-// right-looking scheme as k_potrf, but the two serial pieces of a panel -- which bound it: 7 panels x (diagonal block 3.9 us +
-// panel solve 2.9 us) of 63 us at n = 100 -- are reorganised:
-//   * diagonal 16x16 block: lane = (row i, column group g), 4 entries per lane, processed as 4x4 sub-blocks with one LDS
-//     exchange per sub-block column (instead of 15 v_readlane broadcasts per pivot), and the SAME loop carries a second 16x16
-//     block along that ends up as L11^-1 (right-looking forward substitution on the identity);
-//   * panel solve L21 = A21 L11^-T becomes one 16x16x16 product per row tile on the matrix cores (B operand = L11^-1),
-//     instead of a 136-term dependent substitution per row fed by LDS reads.
-// Using the explicit inverse of the (well-conditioned) 16x16 diagonal block costs ~cond(L11) eps in L21, far inside the
-// parity budget (|L L' - A| stays at 1e-16 |A| in tools/kbench_linalg).
+// LDS-resident Cholesky for n <= 128 (every 1-car configuration), one workgroup of 8 waves per matrix, whole matrix in LDS.
+// The panel step is bound by its two serial pieces, both in linalg_diag.h: the diagonal block (one wave, ~2.0 us) and the panel
+// solve (blocked substitution on the matrix cores); the trailing update overlaps the next diagonal block (look-ahead).
+// History at n = 100: per-pivot diagonal block + per-row substitution 63 us -> 4x4 sub-blocked block with explicit inverse 39 us
+// -> without the inverse (blocked MFMA substitution), one Newton step per pivot, branch-free row selection 29 us.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
                                                    int n, int npad, const double* scale, int* status, int* active) {
@@ -187,25 +68,20 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
     __syncthreads();
     const int li = lane & 15, lk = lane >> 4;
     auto factor_diag_inv = [&](int j0) {
-        const bool bad = diag16_factor_inv(lane,
+        const bool bad = diag16_factor(lane,
             [&](int i, int c) { return W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw]; },
             [&](int i, int c, double v) { W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
         if (bad && lane == 0) failed = 1;
     };
-    // rows r0 .. r0+15 of the panel below the diagonal block: L21 tile = A21 tile * L11^-T on the matrix cores
-    auto panel_tile = [&](int j0, int r0) {
-        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+    // rows r0 .. r0+15 of the panel below the diagonal block: L21 tile = A21 tile * L11^-T on the matrix cores (in place: every lane
+    // writes back exactly the entries it read)
+    auto panel_tile = [&](const PanelOps& o, int j0, int r0) {
+        double a[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const double av = W[(size_t)(r0 + li) + (size_t)(j0 + kk * 4 + lk) * ldw];
-            const double bv = dsh.Li[li][kk * 4 + lk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);       // acc[r] = sum_k Linv[lk+4r][k] A21[r0+li][k]
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                           // every lane has read the tile: overwrite in place
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q = 0; q < 4; ++q) a[q] = W[(size_t)(r0 + li) + (size_t)(j0 + q * 4 + lk) * ldw];
+        panel_solve_tile(o, a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) W[(size_t)(r0 + li) + (size_t)(j0 + lk + 4 * r) * ldw] = acc[r];
+        for (int q = 0; q < 4; ++q) W[(size_t)(r0 + li) + (size_t)(j0 + q * 4 + lk) * ldw] = a[q];
     };
     auto trail_pair = [&](int j0, int t1, int q) {
         int ta = 0, qq = q;
@@ -228,7 +104,10 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
     for (int j0 = 0; j0 < m; j0 += kNB) {
         if (failed) break;
         const int i1 = j0 + kNB, ntile = (m - i1) / 16, t1 = i1 / 16;
-        for (int t = wv; t < ntile; t += NW) panel_tile(j0, i1 + 16 * t);
+        if (wv < ntile) {
+            const PanelOps o = panel_solve_operands(lane, dsh);
+            for (int t = wv; t < ntile; t += NW) panel_tile(o, j0, i1 + 16 * t);
+        }
         __syncthreads();
         if (ntile > 0) {
             const int npair = ntile * (ntile + 1) / 2;
@@ -277,23 +156,21 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
     __threadfence_block();
     __syncthreads();
     auto factor_diag_inv = [&](int j0) {
-        const bool bad = diag16_factor_inv(lane,
+        const bool bad = diag16_factor(lane,
             [&](int i, int c) { return (j0 + i < m && j0 + c < m) ? W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] : ((i == c) ? 1.0 : 0.0); },
             [&](int i, int c, double v) { if (j0 + i < m && j0 + c < m) W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
         if (bad && lane == 0) failed = 1;
     };
-    auto panel_tile = [&](int j0, int r0) {              // L21 tile = A21 tile * L11^-T on the matrix cores; result to W (L2) and P (LDS)
+    auto panel_tile = [&](const PanelOps& o, int j0, int r0) {   // L21 tile = A21 tile * L11^-T on the matrix cores; result to W (L2) and P (LDS)
         const int ra = r0 + li;
-        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
-        double av[4];
+        double a[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { const int col = j0 + kk * 4 + lk; av[kk] = (ra < m && col < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0; }
+        for (int q = 0; q < 4; ++q) { const int col = j0 + q * 4 + lk; a[q] = (ra < m && col < m) ? W[(size_t)ra + (size_t)col * ldw] : 0.0; }
+        panel_solve_tile(o, a);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dsh.Li[li][kk * 4 + lk], av[kk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = lk + 4 * r;
-            if (ra < m) { P[(size_t)ra * kPS + c] = acc[r]; if (j0 + c < m) W[(size_t)ra + (size_t)(j0 + c) * ldw] = acc[r]; }
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * 4 + lk;
+            if (ra < m) { P[(size_t)ra * kPS + c] = a[q]; if (j0 + c < m) W[(size_t)ra + (size_t)(j0 + c) * ldw] = a[q]; }
         }
     };
     auto trail_pair = [&](int j0, int t1, int q) {       // one 16x16 tile of the rank-16 trailing update: pair q -> tile (t1 + ta, t1 + tb), ta >= tb
@@ -321,7 +198,10 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
         if (failed) break;
         const int i1 = j0 + kNB;                          // first row below the panel (>= m after the last, possibly partial, panel)
         const int ntile = (i1 < m) ? (m - i1 + 15) / 16 : 0, t1 = i1 / 16;
-        for (int t = wv; t < ntile; t += NW) panel_tile(j0, i1 + 16 * t);
+        if (wv < ntile) {
+            const PanelOps o = panel_solve_operands(lane, dsh);
+            for (int t = wv; t < ntile; t += NW) panel_tile(o, j0, i1 + 16 * t);
+        }
         __threadfence_block();
         __syncthreads();
         if (ntile > 0) {
@@ -335,19 +215,233 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
     if (failed && tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
 }
 
-void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s) {
-    const int npad = (n + kNB - 1) / kNB * kNB;
+// ---------------------------------------------------------------------------------------------
+// Cooperative variant for matrices that do not fit one CU's LDS (cs = 300): G workgroups ("cluster") per matrix.  A single CU
+// moves ~57 GB/s from L2 and has 1/256 of the chip's FP64 matrix rate -- k_potrf_global spends most of its 234 us on the
+// trailing read-modify-write.  Here the 16-wide block columns (panels) are dealt round-robin to the G workgroups and live in
+// their owner's LDS for the whole factorisation; the only traffic between CUs is each solved panel, once: its owner writes it to
+// the output buffer (where it has to go anyway) with agent-scope write-through stores, drains them, and sets flag[b][j]; the other
+// workgroups poll that flag (one lane, relaxed agent-scope loads), read the panel with agent-scope loads into an LDS strip and
+// update their own panels from it on the matrix cores.  The owner of panel j+1 updates that panel first, factors, solves and
+// publishes it, and only then updates the rest of its panels (look-ahead), so the critical path per panel is one hand-off + one
+// 16x16 factorisation + one panel product.
+// Flags are monotonic: a launch publishes 2*epoch (ok) / 2*epoch + 1 (not positive definite: everybody leaves), epoch = a per
+// workspace launch counter, so they are never reset.  Every wait is bounded (2 s of the 100 MHz clock -> MPOPIS_ERR_HIP): a
+// cluster whose workgroups are not all resident cannot hang the device.  No placement is assumed (any CU / XCD).
+// ---------------------------------------------------------------------------------------------
+#ifdef POTRF_PROF
+__device__ unsigned long long g_prof[8 * 32 * 6];
+void debug_read_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(g_prof)); }
+#define PROF_MARK(g_, j_, k_) do { if (b == 0 && tid == 0) g_prof[((g_) * 32 + (j_)) * 6 + (k_)] = wall_clock64(); } while (0)
+#else
+#define PROF_MARK(g_, j_, k_) do { } while (0)
+#endif
+constexpr int kCoopThreads = 1024, kCoopWaves = kCoopThreads / 64, kCoopMaxOwn = 16, kCoopPS = kNB + 1;
+__device__ __forceinline__ int coop_ld(int rows) { return (rows & 31) ? rows : rows + 16; }   // column stride = 16 mod 32 doubles: the 4 k-groups of an MFMA operand read hit different bank halves
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+
+__global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout, int n, int G,
+                                                             const double* scale, int* status, int* active,
+                                                             unsigned long long* flags, unsigned long long epoch) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ DiagScratch dsh;
+    __shared__ int sh_fail, sh_wait, p_off[kCoopMaxOwn], p_ld[kCoopMaxOwn];
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int npan = (n + kNB - 1) / kNB, npad = npan * kNB;
+    const int nown = (npan - g + G - 1) / G;                       // panels g, g + G, ...
+    const double* Ab = A + (size_t)b * Astride;
+    double* Lb = Lout + (size_t)b * n * n;
+    unsigned long long* fl = flags + (size_t)b * npan;
+    const double sc = scale ? scale[b] : 1.0;
+    const unsigned long long ok_val = 2 * epoch;
+    if (tid == 0) {
+        int off = 0;
+        for (int q = 0; q < nown; ++q) { const int rows = npad - (g + q * G) * kNB; p_off[q] = off; p_ld[q] = coop_ld(rows); off += p_ld[q] * kNB; }
+        sh_fail = 0;
+    }
+    __syncthreads();
+    double* P = smem + p_off[nown - 1] + p_ld[nown - 1] * kNB;      // received panel strip [npad][17]
+    // ---- own panels <- lower(sc * A), identity beyond n -----------------------------------------------------------------------
+    for (int q = 0; q < nown; ++q) {
+        const int c0 = (g + q * G) * kNB, rows = npad - c0, ld = p_ld[q], cnt = rows * kNB;
+        double* W = smem + p_off[q];
+        for (int e0 = tid; e0 < cnt; e0 += kCoopThreads * 4) {
+            double av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + u * kCoopThreads, cnt - 1), i = c0 + e % rows, col = c0 + e / rows;
+                av[u] = Ab[(size_t)min(i, n - 1) + (size_t)min(col, n - 1) * n];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * kCoopThreads;
+                if (e < cnt) { const int il = e % rows, cl = e / rows, i = c0 + il, col = c0 + cl; W[il + cl * ld] = (i < n && col < n) ? sc * av[u] : ((i == col) ? 1.0 : 0.0); }
+            }
+        }
+    }
+    __syncthreads();
+    // operand (row r, k) of panel j: from the owner's own storage or from the received strip
+    auto tile_update = [&](double* Wc, int ldc, int c, int ta, const double* src, int src_ld, int src_row0, bool strip) {
+        // Wc: panel c (local row 0 = global row 16c); tile rows 16 ta ..; src(r, k) = strip ? src[r * 17 + k] : src[(r - src_row0) + k * src_ld]
+        const int r0 = ta * kNB, c0 = c * kNB;
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = kk * 4 + lk;
+            const double av = strip ? src[(size_t)(r0 + li) * kCoopPS + k] : src[(r0 + li - src_row0) + k * src_ld];
+            const double bv = strip ? src[(size_t)(c0 + li) * kCoopPS + k] : src[(c0 + li - src_row0) + k * src_ld];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc, 0, 0, 0);     // acc[r] <-> (row r0 + li, column c0 + lk + 4r)
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Wc[(r0 - c0 + li) + (lk + 4 * r) * ldc] -= acc[r];
+    };
+    // factor the diagonal block of own panel q (= panel c), solve the panel, write it out, publish
+    auto factor_solve_publish = [&](int q, int c) -> bool {
+        double* W = smem + p_off[q];
+        const int ld = p_ld[q], c0 = c * kNB, h = npan - c;
+        if (wv == 0) {
+            const bool bad = diag16_factor(lane, [&](int i, int cc) { return W[i + cc * ld]; }, [&](int i, int cc, double v) { W[i + cc * ld] = v; }, dsh);
+            if (bad && lane == 0) sh_fail = 1;
+        }
+        __syncthreads();
+        PROF_MARK(g, c > 0 ? c - 1 : 31, 5);
+        if (sh_fail) {
+            if (tid == 0) {
+                if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD);
+                if (active) active[b] = 0;
+                for (int jj = c; jj < npan; ++jj) __hip_atomic_store(&fl[jj], ok_val + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return false;
+        }
+        if (1 + wv < h) {
+            const PanelOps o = panel_solve_operands(lane, dsh);
+            for (int t = 1 + wv; t < h; t += kCoopWaves) {        // L21 tile = A21 tile * L11^-T
+                double a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = W[(t * kNB + li) + (q * 4 + lk) * ld];
+                panel_solve_tile(o, a);
+                const int i = c0 + t * kNB + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = q * 4 + lk;
+                    W[(t * kNB + li) + cl * ld] = a[q];
+                    if (i < n && c0 + cl < n) st_agent(&Lb[(size_t)i + (size_t)(c0 + cl) * n], a[q]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&fl[c], ok_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // rows 0 .. 16c+15 of these columns: zeros above the diagonal, the factored diagonal block (nobody in the cluster reads them)
+        for (int e = tid; e < (c0 + kNB) * kNB; e += kCoopThreads) {
+            const int i = e % (c0 + kNB), cl = e / (c0 + kNB);
+            if (i < n && c0 + cl < n) Lb[(size_t)i + (size_t)(c0 + cl) * n] = (i >= c0 + cl) ? W[(i - c0) + cl * ld] : 0.0;
+        }
+        return true;
+    };
+    // wait for panel j and read its rows below the diagonal block into the strip
+    auto receive = [&](int j) -> bool {
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long v;
+            int st = 0;
+            while ((v = __hip_atomic_load(&fl[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ok_val) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 200000000ull) { st = 2; break; }
+            }
+            if (!st && (v & 1)) st = 1;
+            if (st == 2 && status) atomicMin(&status[b], MPOPIS_ERR_HIP);
+            sh_wait = st;
+        }
+        __syncthreads();
+        if (sh_wait) return false;
+        const int r1 = (j + 1) * kNB, rows = npad - r1, cnt = rows * kNB, j0 = j * kNB;
+        for (int e0 = tid; e0 < cnt; e0 += kCoopThreads * 5) {      // one batch of loads in flight for cs = 300 (4608 entries)
+            double av[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int e = min(e0 + u * kCoopThreads, cnt - 1), r = r1 + e % rows, k = e / rows;
+                av[u] = ld_agent(&Lb[(size_t)min(r, n - 1) + (size_t)min(j0 + k, n - 1) * n]);
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int e = e0 + u * kCoopThreads;
+                if (e < cnt) { const int r = r1 + e % rows, k = e / rows; P[(size_t)r * kCoopPS + k] = (r < n && j0 + k < n) ? av[u] : 0.0; }
+            }
+        }
+        __syncthreads();
+        return true;
+    };
+    if (g == 0 && !factor_solve_publish(0, 0)) return;
+    for (int j = 0; j + 1 < npan; ++j) {
+        const bool mine = (j % G) == g;
+        PROF_MARK(g, j, 0);
+        if (!mine && !receive(j)) return;
+        PROF_MARK(g, j, 1);
+        const double* src = mine ? smem + p_off[j / G] : P;
+        const int src_ld = mine ? p_ld[j / G] : 0, src_row0 = j * kNB;
+        const bool nxt = ((j + 1) % G) == g;
+        if (nxt) {
+            const int q = (j + 1) / G, c = j + 1;
+            for (int ta = c + wv; ta < npan; ta += kCoopWaves) tile_update(smem + p_off[q], p_ld[q], c, ta, src, src_ld, src_row0, !mine);
+            __syncthreads();
+            PROF_MARK(g, j, 2);
+            if (!factor_solve_publish(q, c)) return;
+            PROF_MARK(g, j, 3);
+        }
+        // the rest of the owned panels (c > j + 1): tiles dealt to the waves across panels
+        int idx = wv;
+        for (int q = 0; q < nown; ++q) {
+            const int c = g + q * G;
+            if (c <= j + 1) continue;
+            const int h = npan - c;
+            for (; idx < h; idx += kCoopWaves) tile_update(smem + p_off[q], p_ld[q], c, c + idx, src, src_ld, src_row0, !mine);
+            idx -= h;
+        }
+        __syncthreads();
+        PROF_MARK(g, j, 4);
+    }
+}
+
+size_t potrf_coop_flag_words(int B, int n) { return (size_t)B * ((n + kNB - 1) / kNB); }
+
+// coop_flags / coop_epoch: per-handle workspace (potrf_coop_flag_words, zero-initialised once) and launch counter; null -> never cooperative
+void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
+                  unsigned long long* coop_flags, unsigned long long* coop_epoch) {
+    const int npad = (n + kNB - 1) / kNB * kNB, npan = npad / kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
         static std::atomic<unsigned long long> seen{0};
         ensure_dyn_lds((const void*)k_potrf_lds, 150 * 1024, seen);
         hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
-    } else {
-        const size_t strip = (size_t)n * (kNB + 1) * sizeof(double);                         // panel strip
-        static std::atomic<unsigned long long> seen2{0};
-        ensure_dyn_lds((const void*)k_potrf_global, 150 * 1024, seen2);
-        hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active);
+        return;
     }
+    static const int env_G = [] { const char* e = getenv("MPOPIS_POTRF_G"); return e ? atoi(e) : -1; }();
+    int G = env_G >= 0 ? env_G : 6;
+    if (G > npan) G = npan;
+    size_t coop_lds = 0;
+    if (G >= 2 && coop_flags && coop_epoch) {
+        size_t own = 0;                                           // workgroup 0 owns the tallest panels
+        for (int c = 0; c < npan; c += G) { const int rows = npad - c * kNB; own += (size_t)((rows & 31) ? rows : rows + 16) * kNB; }
+        coop_lds = (own + (size_t)npad * kCoopPS) * sizeof(double);
+    }
+    // clusters must be co-resident: one workgroup per CU (LDS), keep the grid well below the chip so that kernels of other streams
+    // cannot starve a cluster forever (they finish on their own; every wait is bounded anyway)
+    if (coop_lds && coop_lds <= 150 * 1024 && (npan + G - 1) / G <= kCoopMaxOwn && B * G <= 128) {
+        static std::atomic<unsigned long long> seen3{0};
+        ensure_dyn_lds((const void*)k_potrf_coop, 150 * 1024, seen3);
+        const unsigned long long epoch = ++*coop_epoch;
+        hipLaunchKernelGGL(k_potrf_coop, dim3(B * G), dim3(kCoopThreads), coop_lds, s, A, Astride, L, n, G, scale, status, active, coop_flags, epoch);
+        return;
+    }
+    const size_t strip = (size_t)n * (kNB + 1) * sizeof(double);                             // panel strip
+    static std::atomic<unsigned long long> seen2{0};
+    ensure_dyn_lds((const void*)k_potrf_global, 150 * 1024, seen2);
+    hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active);
 }
 
 // g = Σ⁻¹ (γ U_orig) through the Cholesky factor (Σ symmetric => row vector γ U_orig' Σ⁻¹ = g').

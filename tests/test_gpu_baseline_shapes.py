@@ -233,3 +233,38 @@ def test_two_stream_overlap_is_bit_identical(eng_mod, track, kind, ncars, K, N):
         outs.append(res)
     for a, b, c in zip(*outs):
         assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_cooperative_cholesky_cs300(eng_mod, track):
+    """cs = 300 (3 cars) does not fit one CU's LDS: k_potrf_coop spreads the block columns over several workgroups that hand
+    panels over through epoch-tagged flags.  (1) a dense SPD Σ: E = L Z against numpy's Cholesky; (2) a Σ whose first bad pivot sits
+    in a late panel (another workgroup than the one that starts): PosDefException (-2), no hang, and the SAME handle then factors a
+    good Σ again (stale / failed flags of earlier launches are ignored); (3) a batch too large for co-resident clusters falls back
+    to the one-workgroup kernel: same controls as the cooperative path."""
+    from mpopis_amd._lib import MPOPISError
+    T, K, cs = 50, 256, 300
+    rng = np.random.default_rng(300)
+    Q = np.linalg.qr(rng.standard_normal((cs, cs)))[0]
+    Sig = (Q * (0.05 * np.logspace(0, -3, cs))) @ Q.T
+    Sig = 0.5 * (Sig + Sig.T)
+    eng = eng_mod.Engine("car", 3, "gmppi", K, T, batch=1, lam=10.0, cov=np.tile([0.0625, 0.1], 3), track=track)
+    Z = rng.standard_normal((1, 1, K, cs))
+    for rep in range(2):
+        eng.set_Sigma(Sig)
+        E = eng.policy_step(Z, want_E=True)["E"][0]
+        Lref = np.linalg.cholesky(Sig)
+        assert E.shape == (K, cs) and np.max(np.abs(E - Z[0, 0] @ Lref.T)) < 1e-12
+        bad = Sig.copy()
+        bad[205, 205] = -1.0                                   # panel 12 of 19
+        with pytest.raises(MPOPISError) as ei:
+            eng.set_Sigma(bad)
+        assert ei.value.code == -2
+    eng.close()
+    outs = []
+    for B in (2, 24):                                          # 24 x 6 workgroups > the co-residency limit -> k_potrf_global
+        eng = eng_mod.Engine("car", 3, "musigmaaismppi", K * 2, T, batch=B, lam=10.0, ais_its=3, lam_ais=20.0, cov=np.tile([0.0625, 0.1], 3), track=track)
+        eng.seed_slots(np.arange(B, dtype=np.uint64) % 2 + 77)
+        got = eng.policy_step(None)
+        outs.append((got["control"][:2].copy(), got["cost"][:2].copy()))
+        eng.close()
+    assert np.max(np.abs(outs[0][0] - outs[1][0])) < 1e-9 and rel_err(outs[0][1], outs[1][1]) < 1e-9

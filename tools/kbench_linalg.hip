@@ -16,6 +16,9 @@ template <class F> float timeit(F f, int reps, hipStream_t s) {
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms / reps * 1e3f;
 }
+#ifdef POTRF_PROF
+namespace mpopis { void debug_read_prof(unsigned long long* out); }
+#endif
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 300;
     hipStream_t s; CK(hipStreamCreate(&s));
@@ -40,11 +43,28 @@ int main(int argc, char** argv) {
     CK(hipMemset(dstatus, 0, B * 4));
     std::vector<int> ones(B, 1); CK(hipMemcpy(dact, ones.data(), B * 4, hipMemcpyHostToDevice));
     printf("B=%d n=%d\n", B, n);
-    printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s); }, 20, s));
+    unsigned long long* dflags; unsigned long long epoch = 0;
+    CK(hipMalloc(&dflags, potrf_coop_flag_words(B, n) * 8)); CK(hipMemset(dflags, 0, potrf_coop_flag_words(B, n) * 8));
+    printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s, dflags, &epoch); }, 20, s));
+#ifdef POTRF_PROF
     {
-        std::vector<double> L(nn); CK(hipMemcpy(L.data(), dL, nn * 8, hipMemcpyDeviceToHost));
-        double err = 0; for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k <= j; ++k) v += L[i + (size_t)k * n] * L[j + (size_t)k * n]; err = fmax(err, fabs(v - A[i + (size_t)j * n])); }
-        double up = 0; for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) up = fmax(up, fabs(L[i + (size_t)j * n]));
+        std::vector<unsigned long long> pr(8 * 32 * 6); mpopis::debug_read_prof(pr.data());
+        const int G = getenv("MPOPIS_POTRF_G") ? atoi(getenv("MPOPIS_POTRF_G")) : 6, npan = (n + 15) / 16;
+        unsigned long long t00 = ~0ull; for (auto v : pr) if (v && v < t00) t00 = v;
+        printf("   step owner(j+1): start recv upd diag publish end   [us, 100 MHz clock]\n");
+        for (int j = 0; j + 1 < npan; ++j) { const int g = (j + 1) % G; const unsigned long long* q = &pr[(g * 32 + j) * 6];
+            printf("   j=%2d g=%d: %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f\n", j, g, (q[0]-t00)*0.01, (q[1]-t00)*0.01, (q[2]-t00)*0.01, (q[5]-t00)*0.01, (q[3]-t00)*0.01, (q[4]-t00)*0.01); }
+    }
+#endif
+    { std::vector<int> st0(B); CK(hipMemcpy(st0.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); int mn = 0; for (int v : st0) mn = v < mn ? v : mn; printf("   potrf status min %d\n", mn); }
+    {
+        std::vector<double> Lall(nn * B); CK(hipMemcpy(Lall.data(), dL, nn * B * 8, hipMemcpyDeviceToHost));
+        double err = 0, up = 0;
+        for (int bb = 0; bb < B; bb += (B > 4 ? B / 4 : 1)) {
+            const double* L = Lall.data() + bb * nn; const double* Ab = A.data() + bb * nn;
+            for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k <= j; ++k) v += L[i + (size_t)k * n] * L[j + (size_t)k * n]; err = fmax(err, fabs(v - Ab[i + (size_t)j * n])); }
+            for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) up = fmax(up, fabs(L[i + (size_t)j * n]));
+        }
         printf("   potrf max |LL'-A| = %.3e, max |upper| = %.1e\n", err, up);
     }
     printf("trtri_fro + lanczos   %8.1f us\n", timeit([&] { launch_invsqrt_vec(dA, dL, nn, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s); }, 20, s));
