@@ -151,11 +151,14 @@ void launch_alias_sample(const double* accept, const int32_t* alias, const int32
 // kernels_cma.hip
 // kernels_invsqrt.hip: y = A^-1/2 b (Lanczos + quadrature) and fro = tr(A^-1) = scale * ||L^-1||_F^2 with L = chol(scale * A)
 constexpr size_t kInvsqrtPadDoubles = 512;
-size_t invsqrt_workspace_doubles(int B, int n);
+size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot = 1);
+int invsqrt_coop_groups(int B, int n);      // workgroups per matrix the cooperative Lanczos would use for this batch (1: not cooperative)
 int invsqrt_max_n();
 void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s);
 void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
-                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);
+                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
+                            int regions_per_slot = 1, unsigned long long* coop_xbuf = nullptr, unsigned long long* coop_epoch = nullptr);
+size_t invsqrt_coop_words(int B, int n);
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
                         double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);
 void launch_cma_begin(double* scal, double* vec, double* sig2, double sigma0, int cs, int B, hipStream_t s);

@@ -137,7 +137,8 @@ int mpopis_handle::ais_update(int n, bool injected) {
         // factor this iteration sampled from (same Σ: the update :598 comes after), so tr(Σ^-1) = σ² ||L^-1||_F²
         if (side) (void)hipStreamWaitEvent(stream, ev_join[0], 0);
         else launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, stream);
-        launch_lanczos_invsqrt(d_Sig, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream);
+        launch_lanczos_invsqrt(d_Sig, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream,
+                               lan_regions, d_lan_x, &coop_epoch);
         launch_cma_paths(d_Cdw, d_fro, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
         launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);
         time_end();

@@ -34,6 +34,13 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// 1/x for a normal-range x: v_rcp_f64 + two Newton steps (<= 1 ulp; an IEEE division is ~25 dependent instructions on a lone wave)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
 constexpr int kTB = 16;                      // block size of the triangular inverse
 constexpr int kInvThreads = 1024, kInvWaves = kInvThreads / 64;
 
@@ -152,36 +159,68 @@ __global__ void __launch_bounds__(kInvThreads) k_trtri_fro(const double* __restr
 constexpr int kLanThreads = 1024, kLanWaves = kLanThreads / 64;
 constexpr int kLanNQ = 5;                    // rows per lane and pass of the mat-vec (64*5 = 320 >= cs = 300 in one pass)
 constexpr int kLanCG = 4;                    // columns whose loads are in flight together
-constexpr int kLanPivLds = 32;               // pivot rows of the final back substitution kept in LDS (longer runs: global workspace)
+constexpr int kLanPivLds = 16;               // pivot rows of the final back substitution kept in LDS (longer runs: global workspace)
 constexpr double kLanTol = 1e-13;
+constexpr int kLanRed = kLanWaves + 4 + 16;  // block-reduction scratch + (COOP) the workgroups' column maxima
 
 // y[b] = A[b]^-1/2 bvec[b];  fro[b] = scale[b] * sum_J part[b][J]  (= tr(A^-1) = ||A^-1/2||_F^2)
 // status: MPOPIS_ERR_NUMERIC when the spectrum bounds are unusable (non-finite input, M/m beyond 1e14)
+//
+// COOP = true: G workgroups per matrix.  One CU reads A at ~57 GB/s from L2, which is what a Lanczos step costs at n = 300 (720 KB
+// per mat-vec: 12.6 of 19 us).  Here workgroup g keeps the columns [g nc, (g+1) nc) of A (= rows, A symmetric) in LDS for the whole
+// run and produces the entries w[c] = A[:, c] . v of its columns; the slices are exchanged through global memory as self-validating
+// 8-byte granules {32 data bits | 32 tag bits} (two per double, both tagged with (launch epoch, step)), written
+// with agent-scope stores straight from the reducing lane and polled by the consumers -- no flag, no drain, no fence.  Everything after the
+// mat-vec (orthogonalisation, stopping rule, quadrature) is replicated: every workgroup holds the full vectors and takes identical
+// decisions on identical bits.  Waits are bounded (2 s -> MPOPIS_ERR_HIP).
+#ifdef LAN_PROF
+__device__ unsigned long long g_lprof[64 * 8];
+void debug_read_lprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lprof), sizeof(g_lprof)); }
+#define LPROF(j_, k_) do { if (blockIdx.x == 0 && tid == 0 && (j_) < 64) g_lprof[(j_) * 8 + (k_)] = wall_clock64(); } while (0)
+#else
+#define LPROF(j_, k_) do { } while (0)
+#endif
+template <bool COOP>
 __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
                                                                  const double* __restrict__ part, int nb, const double* __restrict__ scale,
                                                                  double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
-                                                                 int* __restrict__ msteps, int n, int nvl, int* status, const int* active) {
+                                                                 int* __restrict__ msteps, int n, int nvl, int* status, const int* active,
+                                                                 int G, int Gs, unsigned long long* xbuf, unsigned long long epoch) {
     MPOPIS_HI_PRIO();
-    const int b = blockIdx.x;
+    const int b = COOP ? blockIdx.x / G : blockIdx.x, g = COOP ? blockIdx.x % G : 0;
     if (active && !active[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh_lan[];
-    double* part_v = sh_lan;                            // [kLanWaves][n]
-    double* vcur = part_v + (size_t)kLanWaves * n;      // [n]
+    const int nc = COOP ? (n + G - 1) / G : 0, c_lo = g * nc, c_hi = min(n, c_lo + nc);       // own columns (COOP)
+    double* part_v = sh_lan;                            // [kLanWaves][n]  (COOP: the column slab [nc][n])
+    double* vcur = part_v + (COOP ? (size_t)nc * n : (size_t)kLanWaves * n);      // [n]
     double* wv_ = vcur + n;                             // [n]  the working vector w
     double* coef = wv_ + n;                             // [n + 1]
     double* alpha = coef + n + 1;                       // [n]
     double* beta = alpha + n;                           // [n]
     double* cvec = beta + n;                            // [n]
-    double* red = cvec + n;                             // [kLanWaves + 4]
-    double* pivl = red + kLanWaves + 4;                 // [2][kLanPivLds][64]  d_i and e_i = β_i/d_i of the back substitution
+    double* red = cvec + n;                             // [kLanRed]
+    double* pivl = red + kLanRed;                 // [2][kLanPivLds][64]  d_i and e_i = β_i/d_i of the back substitution
     double* Vl = pivl + 2 * kLanPivLds * 64;            // [nvl][n]  Lanczos basis, LDS-resident part
     __shared__ int sh_flag;
     const double* A = Aall + (size_t)b * n * n;
     const double* bv = bvec + (size_t)b * bstride;
-    double* Vg = Vall + (size_t)b * (size_t)(n + 1 + 128) * n;  // basis vectors v_0 .. v_n (only k >= nvl are ever touched)
+    double* Vg = Vall + ((size_t)b * Gs + g) * (size_t)(n + 1 + 128) * n;  // basis vectors v_0 .. v_n (only k >= nvl are ever touched); Gs regions per slot
     double* pivg = Vg + (size_t)(n + 1) * n;                    // [2][n][64]
     double* y = yall + (size_t)b * n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool writer = !COOP || g == 0;                        // replicated results: one workgroup writes them
+    unsigned long long* xb = COOP ? xbuf + (size_t)b * 4 * (n + G) : nullptr;     // [2 parities][n + G][2 granules]
+    if (COOP) {                                                 // slab <- own columns (contiguous in memory), 8 loads in flight per thread
+        const double* src = A + (size_t)c_lo * n;
+        const int cnt = (c_hi - c_lo) * n;
+        for (int e0 = tid; e0 < cnt; e0 += kLanThreads * 8) {
+            double av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = src[min(e0 + u * kLanThreads, cnt - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (e0 + u * kLanThreads < cnt) part_v[e0 + u * kLanThreads] = av[u];
+        }
+    }
     auto block_sum = [&](double v) -> double {
         v = wave_sum(v);
         __syncthreads();
@@ -195,66 +234,137 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     double fro = 0.0;
     for (int J = 0; J < nb; ++J) fro += part[(size_t)b * nb + J];
     fro *= scale ? scale[b] : 1.0;
-    if (tid == 0) fro_out[b] = fro;
+    if (tid == 0 && writer) fro_out[b] = fro;
     // ---- v_0 = b / ||b|| --------------------------------------------------------------------------------------------------
     double s2 = 0.0;
     for (int i = tid; i < n; i += kLanThreads) { const double v = bv[i]; s2 = fma(v, v, s2); }
     const double nrm_b = sqrt(block_sum(s2));
     if (!(nrm_b > 0.0) || !(fro > 0.0)) {                             // δw = 0 -> y = 0; NaN input / unusable trace -> numeric error
-        for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-        if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) status[b] = MPOPIS_ERR_NUMERIC; }
+        if (writer) {
+            for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
+            if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) status[b] = MPOPIS_ERR_NUMERIC; }
+        }
         return;
     }
     for (int i = tid; i < n; i += kLanThreads) { const double v = bv[i] / nrm_b; vcur[i] = v; if (nvl > 0) Vl[i] = v; else Vg[i] = v; }
     __syncthreads();
     const int mcap = n;
     int m = 0;
-    double Mhi = 0.0, mlo = 0.0, q_shift = 0.0, q_weight = 0.0, d_prev = 1.0, g_prev = 0.0;   // quadrature node + pivot recurrence of this lane
+    double Mhi = 0.0, mlo = 0.0, q_shift = 0.0, q_weight = 0.0, q_wres = 0.0, rd_prev = 1.0, g_prev = 0.0;   // quadrature node + pivot recurrence of this lane
     for (int j = 0; j < mcap; ++j) {
         // ---- w = A v_j : lanes along rows (coalesced column reads), waves split the columns, kLanCG columns of loads in flight ----
         double colmax = 0.0;
-        for (int r0 = 0; r0 < n; r0 += 64 * kLanNQ) {
-            double acc[kLanNQ];
-#pragma unroll
-            for (int q = 0; q < kLanNQ; ++q) acc[q] = 0.0;
-            for (int c0 = wv; c0 < n; c0 += kLanWaves * kLanCG) {
-                double a[kLanCG][kLanNQ];
-#pragma unroll
-                for (int u = 0; u < kLanCG; ++u) {
-                    // wave-uniform column base + one lane offset + immediate 512 q: rows past n read into the next column / the
-                    // padding behind the last slot (launch_invsqrt_vec's contract) and are never used
-                    const double* col = A + (size_t)min(c0 + kLanWaves * u, n - 1) * n + r0;
-#pragma unroll
-                    for (int q = 0; q < kLanNQ; ++q) a[u][q] = col[lane + 64 * q];
+        LPROF(j, 0);
+        if constexpr (COOP) {
+            // own columns: w[c] = A[:, c] . v from the LDS slab, one wave per column (up to 3 columns per wave interleaved); the
+            // reducing lane stores the entry to LDS and publishes it as a granule pair
+            // BOTH granules of a pair carry the same 32-bit tag (22 epoch bits | step + 1): each 8-byte store is atomic, so a granule is
+            // either this step's or an older one's, and an older one never has this tag (the host clears the buffer when the epoch bits wrap)
+            const unsigned long long tlo = ((unsigned long long)(((unsigned)(epoch & 0x3fffffull) << 10) | (unsigned)(j + 1))) << 32, thi = tlo;
+            unsigned long long* xp = xb + (size_t)(j & 1) * 2 * (n + G);
+            auto publish = [&](int idx, double v) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                __hip_atomic_store(&xp[2 * idx], (bits & 0xffffffffull) | tlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&xp[2 * idx + 1], (bits >> 32) | thi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            for (int cb = c_lo + wv; cb < c_hi; cb += 3 * kLanWaves) {
+                double s0 = 0.0, s1 = 0.0, s2c = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                const int c1 = cb + kLanWaves, c2 = cb + 2 * kLanWaves;
+                for (int i = lane; i < n; i += 64) {
+                    const double vi = vcur[i];
+                    const double x0 = part_v[(size_t)(cb - c_lo) * n + i];
+                    const double x1 = (c1 < c_hi) ? part_v[(size_t)(c1 - c_lo) * n + i] : 0.0;
+                    const double x2 = (c2 < c_hi) ? part_v[(size_t)(c2 - c_lo) * n + i] : 0.0;
+                    s0 = fma(x0, vi, s0); s1 = fma(x1, vi, s1); s2c = fma(x2, vi, s2c);
+                    if (j == 0) { a0 += fabs(x0); a1 += fabs(x1); a2 += fabs(x2); }
                 }
-#pragma unroll
-                for (int u = 0; u < kLanCG; ++u) {
-                    const int c = c0 + kLanWaves * u;
-                    const double vc = (c < n) ? vcur[c] : 0.0;
-#pragma unroll
-                    for (int q = 0; q < kLanNQ; ++q) acc[q] = fma(a[u][q], vc, acc[q]);
-                    if (j == 0 && c < n) {                                      // first pass: ||A||_inf (A symmetric: column abs sums)
-                        double sa = 0.0;
-#pragma unroll
-                        for (int q = 0; q < kLanNQ; ++q) if (r0 + lane + 64 * q < n) sa += fabs(a[u][q]);
-                        colmax = fmax(colmax, wave_sum(sa));                    // (exact for n <= 64 kLanNQ; larger n: per-chunk sums, see below)
-                    }
+                s0 = wave_sum(s0); s1 = wave_sum(s1); s2c = wave_sum(s2c);
+                if (j == 0) colmax = fmax(colmax, fmax(wave_sum(a0), fmax(wave_sum(a1), wave_sum(a2))));
+                if (lane == 0) {
+                    wv_[cb] = s0; publish(cb, s0);
+                    if (c1 < c_hi) { wv_[c1] = s1; publish(c1, s1); }
+                    if (c2 < c_hi) { wv_[c2] = s2c; publish(c2, s2c); }
                 }
             }
+            if (j == 0) {                                        // ||A||_inf: the workgroup's column maximum travels with the first exchange
+                __syncthreads();
+                if (lane == 0) red[wv] = colmax;
+                __syncthreads();
+                if (tid == 0) { double t = 0.0; for (int w = 0; w < kLanWaves; ++w) t = fmax(t, red[w]); red[kLanWaves + 1 + 0] = t; publish(n + g, t); }
+            }
+            // the other workgroups' entries (and, at j = 0, their column maxima): one thread per entry polls its granule pair
+            LPROF(j, 1);
+            int timed_out = 0;
+            const int nx = (j == 0) ? n + G : n;
+            for (int idx = tid; idx < nx; idx += kLanThreads) {
+                const bool own = (idx < n) ? (idx >= c_lo && idx < c_hi) : (idx - n == g);
+                if (own) continue;
+                unsigned long long lo, hi;
+                const unsigned long long t0 = wall_clock64();
+                unsigned spins = 0;
+                for (;;) {
+                    lo = __hip_atomic_load(&xp[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hi = __hip_atomic_load(&xp[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((lo & 0xffffffff00000000ull) == tlo && (hi & 0xffffffff00000000ull) == thi) break;
+                    if ((++spins & 255u) == 0 && wall_clock64() - t0 > 200000000ull) { timed_out = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const double v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+                if (idx < n) wv_[idx] = v; else red[kLanWaves + 4 + (idx - n)] = v;
+            }
+            if (__syncthreads_or(timed_out)) {
+                if (tid == 0) atomicMin(&status[b], MPOPIS_ERR_HIP);
+                return;
+            }
+            if (j == 0) {
+                double t = red[kLanWaves + 1];
+                for (int q = 0; q < G; ++q) if (q != g) t = fmax(t, red[kLanWaves + 4 + q]);
+                colmax = t;                                     // identical in every workgroup
+            }
+        } else {
+        for (int r0 = 0; r0 < n; r0 += 64 * kLanNQ) {
+                double acc[kLanNQ];
 #pragma unroll
-            for (int q = 0; q < kLanNQ; ++q) if (r0 + lane + 64 * q < n) part_v[(size_t)wv * n + r0 + lane + 64 * q] = acc[q];
-        }
-        __syncthreads();
-        for (int i = tid; i < n; i += kLanThreads) {
-            double s = 0.0;
+                for (int q = 0; q < kLanNQ; ++q) acc[q] = 0.0;
+                for (int c0 = wv; c0 < n; c0 += kLanWaves * kLanCG) {
+                    double a[kLanCG][kLanNQ];
 #pragma unroll
-            for (int w = 0; w < kLanWaves; ++w) s += part_v[(size_t)w * n + i];
-            wv_[i] = s;
+                    for (int u = 0; u < kLanCG; ++u) {
+                        // wave-uniform column base + one lane offset + immediate 512 q: rows past n read into the next column / the
+                        // padding behind the last slot (launch_invsqrt_vec's contract) and are never used
+                        const double* col = A + (size_t)min(c0 + kLanWaves * u, n - 1) * n + r0;
+#pragma unroll
+                        for (int q = 0; q < kLanNQ; ++q) a[u][q] = col[lane + 64 * q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kLanCG; ++u) {
+                        const int c = c0 + kLanWaves * u;
+                        const double vc = (c < n) ? vcur[c] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < kLanNQ; ++q) acc[q] = fma(a[u][q], vc, acc[q]);
+                        if (j == 0 && c < n) {                                      // first pass: ||A||_inf (A symmetric: column abs sums)
+                            double sa = 0.0;
+#pragma unroll
+                            for (int q = 0; q < kLanNQ; ++q) if (r0 + lane + 64 * q < n) sa += fabs(a[u][q]);
+                            colmax = fmax(colmax, wave_sum(sa));                    // (exact for n <= 64 kLanNQ; larger n: per-chunk sums, see below)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < kLanNQ; ++q) if (r0 + lane + 64 * q < n) part_v[(size_t)wv * n + r0 + lane + 64 * q] = acc[q];
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += kLanThreads) {
+                double s = 0.0;
+#pragma unroll
+                for (int w = 0; w < kLanWaves; ++w) s += part_v[(size_t)w * n + i];
+                wv_[i] = s;
+            }
         }
         if (j == 0) {
             // M >= λ_max: max column abs sum; for n > 64 kLanNQ a column's sum is split over row chunks, so bound it by the number of
             // chunks times the largest chunk sum (still an upper bound, only looser)
-            const int nchunk = (n + 64 * kLanNQ - 1) / (64 * kLanNQ);
+            const int nchunk = COOP ? 1 : (n + 64 * kLanNQ - 1) / (64 * kLanNQ);
             __syncthreads();
             if (lane == 0) red[wv] = colmax;
             __syncthreads();
@@ -264,12 +374,16 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             Mhi = t * nchunk;
             mlo = fmin(1.0 / fro, 0.5 * Mhi);
             if (!invsqrt_quad_node(mlo, Mhi, lane, 64, &q_shift, &q_weight)) {       // uniform: depends on mlo / Mhi only
-                for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-                if (tid == 0) { msteps[b] = 0; status[b] = MPOPIS_ERR_NUMERIC; }
+                if (writer) {
+                    for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
+                    if (tid == 0) { msteps[b] = 0; status[b] = MPOPIS_ERR_NUMERIC; }
+                }
                 return;
             }
+            q_wres = q_weight / (mlo + q_shift);                 // residual -> error weight of this lane's node
         }
         __syncthreads();
+        LPROF(j, 2);
         // ---- orthogonalise against v_0..v_j twice (classical Gram-Schmidt, CGS2); α_j = the v_j coefficient -------------------
         double a_j = 0.0;
         const int jl = min(j + 1, nvl);                                             // vectors 0 .. jl-1 in LDS, jl .. j in global memory
@@ -291,6 +405,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             }
             __syncthreads();
         }
+        LPROF(j, 3);
         double w2 = 0.0;
         for (int i = tid; i < n; i += kLanThreads) { const double v = wv_[i]; w2 = fma(v, v, w2); }
         const double bt = sqrt(block_sum(w2));
@@ -300,34 +415,38 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         //      (g_1 = 1/d_1); residual of node j's shifted system = β_m |z_m|, error <= sum_j w_j β_m |z_m| / (λ_min + s_j)  (per unit ||b||)
         {
             const double bprev = (j > 0) ? beta[j - 1] : 0.0;                        // written one step (and several barriers) ago
-            const double d = a_j + q_shift - ((j > 0) ? bprev * bprev / d_prev : 0.0);
-            const double gcur = (j > 0) ? -bprev * g_prev / d : 1.0 / d;
-            d_prev = d; g_prev = gcur;
-            const double eb = bt * wave_sum(q_weight * fabs(gcur) / (mlo + q_shift));
+            const double d = a_j + q_shift - ((j > 0) ? bprev * bprev * rd_prev : 0.0);
+            const double rd = fast_rcp(d);
+            const double gcur = (j > 0) ? -bprev * g_prev * rd : rd;
+            rd_prev = rd; g_prev = gcur;
+            const double eb = bt * wave_sum(q_wres * fabs(gcur));
             const bool conv = (eb <= kLanTol * (1.0 / sqrt(Mhi))) || (bt <= 1e-14 * Mhi) || (m >= mcap);
             if (tid == 0) sh_flag = conv ? 1 : 0;
         }
         __syncthreads();
+        LPROF(j, 4);
         if (sh_flag) break;
+        const double rbt = fast_rcp(bt);
         for (int i = tid; i < n; i += kLanThreads) {
-            const double v = wv_[i] / bt;
+            const double v = wv_[i] * rbt;
             vcur[i] = v;
             if (j + 1 < nvl) Vl[(size_t)(j + 1) * n + i] = v; else Vg[(size_t)(j + 1) * n + i] = v;
         }
         __syncthreads();
     }
+    LPROF(m, 0);
     // ---- c = sum_nodes w (T_m + s I)^-1 e_1: LDL' per node (lane), forward g_i, back z_i = g_i - e_i z_{i+1}; wave 0 -----------------
     if (wv == 0) {
         auto dpiv = [&](int i) -> double& { return i < kLanPivLds ? pivl[i * 64 + lane] : pivg[(size_t)i * 64 + lane]; };
         auto epiv = [&](int i) -> double& { return i < kLanPivLds ? pivl[(kLanPivLds + i) * 64 + lane] : pivg[((size_t)n + i) * 64 + lane]; };
-        double d = 1.0, g = 0.0;
+        double rd = 1.0, g = 0.0;                                                    // rd = 1 / d_{i-1}
         for (int i = 0; i < m; ++i) {
             const double bp = (i > 0) ? beta[i - 1] : 0.0;
-            const double dn = alpha[i] + q_shift - ((i > 0) ? bp * bp / d : 0.0);
-            g = (i > 0) ? -bp * g / dn : 1.0 / dn;
-            d = dn;
+            const double dn = alpha[i] + q_shift - ((i > 0) ? bp * bp * rd : 0.0);
+            rd = fast_rcp(dn);
+            g = (i > 0) ? -bp * g * rd : rd;
             dpiv(i) = g;                                                            // g_i
-            epiv(i) = (i + 1 < m) ? beta[i] / dn : 0.0;                              // e_i = β_i / d_i
+            epiv(i) = (i + 1 < m) ? beta[i] * rd : 0.0;                              // e_i = β_i / d_i
         }
         double z = 0.0;
         for (int i = m - 1; i >= 0; --i) {
@@ -342,15 +461,16 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         double s = 0.0;
         for (int k = 0; k < ml; ++k) s = fma(cvec[k], Vl[(size_t)k * n + i], s);
         for (int k = ml; k < m; ++k) s = fma(cvec[k], Vg[(size_t)k * n + i], s);
-        y[i] = nrm_b * s;
+        if (writer) y[i] = nrm_b * s;
     }
-    if (tid == 0) msteps[b] = m;
+    if (tid == 0 && writer) msteps[b] = m;
+    LPROF(m, 1);
 }
 
-size_t invsqrt_workspace_doubles(int B, int n) { return (size_t)B * (size_t)(n + 1 + 128) * n; }
+size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot) { return (size_t)B * regions_per_slot * (size_t)(n + 1 + 128) * n; }   // cooperative runs: one spill region per workgroup
 int invsqrt_max_n() {
     // dynamic LDS of k_lanczos_invsqrt: (kLanWaves + 6) n + ... doubles, and of k_trtri_fro: 32 (n + 15) + 4112 doubles, both <= 150 KiB
-    return std::min((int)((150 * 1024 / 8 - 64 - 2 * kLanPivLds * 64) / (kLanWaves + 8)), (int)((150 * 1024 / 8 - 4112) / 32 - 15));
+    return std::min((int)((150 * 1024 / 8 - 64 - kLanRed - 2 * kLanPivLds * 64) / (kLanWaves + 8)), (int)((150 * 1024 / 8 - 4112) / 32 - 15));
 }
 
 // y = A^-1/2 b and fro = tr(A^-1) per slot, from A (n x n, SPD) and the Cholesky factor L of scale*A (scale: per-slot, nullable).
@@ -364,22 +484,46 @@ void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int 
     hipLaunchKernelGGL(k_trtri_fro, dim3(nb, B), dim3(kInvThreads), lds1, s, L, Lstride, n, nb, part, active);
 }
 
-// y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound)
+// y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound).
+// xbuf / epoch (nullable): exchange buffer (invsqrt_coop_words, zero-initialised once) and launch counter of the cooperative variant.
+size_t invsqrt_coop_words(int B, int n) { return (size_t)B * 4 * (n + 16); }
+int invsqrt_coop_groups(int B, int n) {
+    static const int env_G = [] { const char* e = getenv("MPOPIS_LANCZOS_G"); return e ? atoi(e) : -1; }();
+    int G = env_G >= 0 ? env_G : 8;
+    if (G > 16) G = 16;
+    if (G < 2 || n < 160 || n > 1000 || B * G > 128) return 1;                 // small matrices: one CU streams them from L2 fast enough; clusters must be co-resident
+    const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
+    return (fixed + (size_t)4 * n) * sizeof(double) <= 150 * 1024 ? G : 1;
+}
 void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
-                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
+                            double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
+                            int regions_per_slot, unsigned long long* xbuf, unsigned long long* epoch) {
     const int nb = (n + kTB - 1) / kTB;
-    static std::atomic<unsigned long long> seen2{0};
-    const size_t fixed = (size_t)(kLanWaves + 6) * n + 1 + kLanWaves + 4 + 2 * kLanPivLds * 64;        // doubles
+    static std::atomic<unsigned long long> seen2{0}, seen3{0};
+    const int G = (xbuf && epoch) ? std::min(invsqrt_coop_groups(B, n), regions_per_slot) : 1;
+    if (G > 1) {
+        const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
+        const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);
+        const size_t lds = (fixed + (size_t)nvl * n) * sizeof(double);
+        ensure_dyn_lds((const void*)k_lanczos_invsqrt<true>, 150 * 1024, seen3);
+        const unsigned long long ep = ++*epoch;
+        if ((ep & 0x3fffffull) == 0) (void)hipMemsetAsync(xbuf, 0, invsqrt_coop_words(B, n) * sizeof(unsigned long long), s);   // tag wrap: no stale granule may alias
+        hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl,
+                           status, active, G, regions_per_slot, xbuf, ep);
+        return;
+    }
+    const size_t fixed = (size_t)(kLanWaves + 6) * n + 1 + kLanRed + 2 * kLanPivLds * 64;               // doubles
     const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);            // basis vectors that fit next to it
     const size_t lds2 = (fixed + (size_t)nvl * n) * sizeof(double);
-    ensure_dyn_lds((const void*)k_lanczos_invsqrt, 150 * 1024, seen2);
-    hipLaunchKernelGGL(k_lanczos_invsqrt, dim3(B), dim3(kLanThreads), lds2, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl, status, active);
+    ensure_dyn_lds((const void*)k_lanczos_invsqrt<false>, 150 * 1024, seen2);
+    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds2, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl,
+                       status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull);
 }
 
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
                         double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
     launch_trtri_fro(L, Lstride, part, B, n, active, s);
-    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s);
+    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s, 1, nullptr, nullptr);
 }
 
 }  // namespace mpopis

@@ -17,7 +17,7 @@ template <class F> float timeit(F f, int reps, hipStream_t s) {
     return ms / reps * 1e3f;
 }
 #ifdef POTRF_PROF
-namespace mpopis { void debug_read_prof(unsigned long long* out); }
+namespace mpopis { void debug_read_prof(unsigned long long* out); void debug_read_lprof(unsigned long long* out); }
 #endif
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 300;
@@ -37,7 +37,8 @@ int main(int argc, char** argv) {
     }
     double *dA, *dL, *db, *dpart, *dV, *dy, *dfro; int *dstatus, *dact, *dm;
     CK(hipMalloc(&dA, (nn * B + kInvsqrtPadDoubles) * 8)); CK(hipMalloc(&dL, nn * B * 8)); CK(hipMalloc(&db, (size_t)B * n * 8));
-    CK(hipMalloc(&dpart, (size_t)B * ((n + 15) / 16) * 8)); CK(hipMalloc(&dV, invsqrt_workspace_doubles(B, n) * 8));
+    CK(hipMalloc(&dpart, (size_t)B * ((n + 15) / 16) * 8)); const int lanG = invsqrt_coop_groups(B, n); CK(hipMalloc(&dV, invsqrt_workspace_doubles(B, n, lanG) * 8));
+    unsigned long long* dlx; CK(hipMalloc(&dlx, invsqrt_coop_words(B, n) * 8)); CK(hipMemset(dlx, 0, invsqrt_coop_words(B, n) * 8)); unsigned long long lep = 0;
     CK(hipMalloc(&dy, (size_t)B * n * 8)); CK(hipMalloc(&dfro, B * 8)); CK(hipMalloc(&dstatus, B * 4)); CK(hipMalloc(&dact, B * 4)); CK(hipMalloc(&dm, B * 4));
     CK(hipMemcpy(dA, A.data(), nn * B * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, bv.data(), (size_t)B * n * 8, hipMemcpyHostToDevice));
     CK(hipMemset(dstatus, 0, B * 4));
@@ -67,7 +68,33 @@ int main(int argc, char** argv) {
         }
         printf("   potrf max |LL'-A| = %.3e, max |upper| = %.1e\n", err, up);
     }
-    printf("trtri_fro + lanczos   %8.1f us\n", timeit([&] { launch_invsqrt_vec(dA, dL, nn, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s); }, 20, s));
+    printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s); }, 20, s));
+    if (getenv("KB_LANCZOS_ONCE")) {
+        launch_trtri_fro(dL, nn, dpart, B, n, dact, s);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
+        hipEventRecord(e1, s); CK(hipStreamSynchronize(s)); float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<int> m1(B), st1(B); CK(hipMemcpy(m1.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st1.data(), dstatus, B * 4, hipMemcpyDeviceToHost));
+        printf("one lanczos launch (G = %d): %.3f ms, m[0] = %d, status[0] = %d\n", lanG, ms, m1[0], st1[0]);
+#ifdef POTRF_PROF
+        { std::vector<unsigned long long> lp(64 * 8); mpopis::debug_read_lprof(lp.data()); const unsigned long long t00 = lp[0];
+          printf("   step: start | matvec+publish | exchange | cgs2 | norm+stop | (us since kernel's first step)\n");
+          for (int j = 0; j <= m1[0] && j < 64; ++j) printf("   j=%2d %7.2f %7.2f %7.2f %7.2f %7.2f\n", j, (lp[j*8]-t00)*0.01, (lp[j*8+1]-t00)*0.01, (lp[j*8+2]-t00)*0.01, (lp[j*8+3]-t00)*0.01, (lp[j*8+4]-t00)*0.01); }
+#endif
+        std::vector<unsigned long long> xb(4 * (n + lanG)); CK(hipMemcpy(xb.data(), dlx, xb.size() * 8, hipMemcpyDeviceToHost));
+        for (int i : {0, 1, 37, 38, 39, 150, 299, 300, 301, 307}) if (i < n + lanG) printf("   x[%d] = %016llx %016llx | parity1 %016llx %016llx\n", i, xb[2 * i], xb[2 * i + 1], xb[2 * (n + lanG) + 2 * i], xb[2 * (n + lanG) + 2 * i + 1]);
+        return 0;
+    }
+    printf("lanczos (G = %d)       %8.1f us\n", lanG, timeit([&] { launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep); }, 20, s));
+    {   // y against the one-workgroup kernel
+        std::vector<double> y1((size_t)B * n), y0((size_t)B * n);
+        CK(hipMemcpy(y1.data(), dy, y1.size() * 8, hipMemcpyDeviceToHost));
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, 1, nullptr, nullptr);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(y0.data(), dy, y0.size() * 8, hipMemcpyDeviceToHost));
+        double d = 0, nr = 0; for (size_t i = 0; i < y0.size(); ++i) { d = fmax(d, fabs(y1[i] - y0[i])); nr = fmax(nr, fabs(y0[i])); }
+        printf("   lanczos coop vs single: max |dy| = %.3e (|y| max %.3e)\n", d, nr);
+    }
     std::vector<int> m(B), st(B); std::vector<double> fro(B);
     CK(hipMemcpy(m.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fro.data(), dfro, B * 8, hipMemcpyDeviceToHost));
     printf("   Lanczos steps m = %d %d ..., status %d, tr(A^-1) = %.6e\n", m[0], m[B > 1 ? 1 : 0], st[0], fro[0]);
