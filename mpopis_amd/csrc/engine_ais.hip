@@ -108,8 +108,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
             (void)hipEventRecord(ev_join[0], xstream[0]);
         }
         time_begin(5);
-        launch_sortperm(d_cost, d_order, B, K, d_active, stream);                             // :455 / :563
-        launch_elite_break(d_cost, d_order, B, K, m_elite, d_active, stream);                 // :458-461 / :566-569
+        launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream);                    // :455 / :563 and the early break :458-461 / :566-569
         time_end();
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
             time_begin(4);

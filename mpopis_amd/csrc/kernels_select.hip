@@ -7,10 +7,98 @@
 
 namespace mpopis {
 
-// Bitonic sort of (cost, index) pairs under the total order (cost asc, index asc) == Julia's stable
-// sortperm.  n = next pow2 >= K, padded with (+inf, big index).
+// CE/CMA early break (:458-461 / :566-569), fused into the sort kernels: if max_j |c[order[j+1]] - c[order[j]]| < 10e-3 over the elite
+// set, the slot leaves the AIS loop (active[b] = 0) -- nothing of this iteration's update is applied.  skey: the sorted costs in LDS
+// (visible to the whole workgroup); m_elite <= 0: no check.
+__device__ __forceinline__ void elite_break_tail(const double* skey, int m_elite, int* active, int b) {
+    __shared__ double eb_red[16];
+    if (m_elite < 2 || !active) return;
+    double mx = -INFINITY;
+    for (int j = threadIdx.x; j + 1 < m_elite; j += blockDim.x) mx = fmax(mx, fabs(skey[j + 1] - skey[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) eb_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) mx = fmax(mx, eb_red[w]);
+        if (mx < 10e-3) active[b] = 0;
+    }
+}
+
+// Bitonic sort of (cost, index) pairs under the total order (cost asc, index asc) == Julia's stable sortperm.
+// n = next pow2 >= max(K, 64), padded with (+inf, index).  Thread t keeps the EPT consecutive entries t EPT .. t EPT + EPT-1 in
+// registers: compare-exchange steps with stride < EPT stay inside the thread, strides < 64 EPT are wave shuffles (no barrier), only
+// the strides that cross waves (>= 64 EPT: 10 of the 78 steps at n = 4096) go through LDS with a barrier.  (The all-LDS version
+// with one barrier per step took 57 us at K = 4096.)
+template <int EPT>
 __global__ void __launch_bounds__(1024) k_sortperm(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int n,
-                                                   const int* active) {
+                                                   int m_elite, int* active) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* key_l = reinterpret_cast<double*>(smem);
+    int32_t* idx_l = reinterpret_cast<int32_t*>(smem + (size_t)n * sizeof(double));
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int base = threadIdx.x * EPT;
+    double k[EPT];
+    int id[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) { const int e = base + r; k[r] = (e < K) ? cost[(size_t)b * K + e] : INFINITY; id[r] = e; }
+    // a <- min(a, b) if keep_min else max(a, b), under (key, index) order (indices are distinct: never equal)
+    auto cmpx = [](double& ka, int& ia, double kb, int ib, bool keep_min) {
+        const bool a_gt_b = (ka > kb) || (ka == kb && ia > ib);
+        if (a_gt_b == keep_min) { ka = kb; ia = ib; }
+    };
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride < EPT) {                                             // inside the thread (compile-time register pairs)
+#pragma unroll
+                for (int S = 1; S < EPT; S <<= 1) {
+                    if (stride == S) {
+#pragma unroll
+                        for (int r = 0; r < EPT; ++r) {
+                            if ((r & S) == 0) {
+                                const bool up = (((base + r) & size) == 0);
+                                const bool a_gt_b = (k[r] > k[r + S]) || (k[r] == k[r + S] && id[r] > id[r + S]);
+                                if (a_gt_b == up) { const double tk = k[r]; k[r] = k[r + S]; k[r + S] = tk; const int ti = id[r]; id[r] = id[r + S]; id[r + S] = ti; }
+                            }
+                        }
+                    }
+                }
+            } else if (stride < EPT * 64) {                                 // inside the wave
+                const int lm = stride / EPT;
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) {
+                    const double kb = __shfl_xor(k[r], lm, 64);
+                    const int ib = __shfl_xor(id[r], lm, 64);
+                    const int e = base + r;
+                    cmpx(k[r], id[r], kb, ib, ((e & stride) == 0) == ((e & size) == 0));
+                }
+            } else {                                                        // across waves
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) { key_l[base + r] = k[r]; idx_l[base + r] = id[r]; }
+                __syncthreads();
+                const int pb = base ^ stride;
+#pragma unroll
+                for (int r = 0; r < EPT; ++r) {
+                    const int e = base + r;
+                    cmpx(k[r], id[r], key_l[pb + r], idx_l[pb + r], ((e & stride) == 0) == ((e & size) == 0));
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) { if (base + r < K) order[(size_t)b * K + base + r] = id[r]; key_l[base + r] = k[r]; }
+    __syncthreads();
+    elite_break_tail(key_l, m_elite, active, b);
+}
+
+// All-LDS bitonic network, one barrier per compare-exchange step: fastest for the mid sizes (n = 512, 1024), where the wave
+// shuffles of the register version cost more than its saved barriers.
+__global__ void __launch_bounds__(1024) k_sortperm_lds(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int n,
+                                                       int m_elite, int* active) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* key = reinterpret_cast<double*>(smem);
@@ -34,39 +122,48 @@ __global__ void __launch_bounds__(1024) k_sortperm(const double* __restrict__ co
         }
     }
     for (int i = threadIdx.x; i < K; i += blockDim.x) order[(size_t)b * K + i] = idx[i];
+    elite_break_tail(key, m_elite, active, b);
 }
 
-void launch_sortperm(const double* cost, int32_t* order, int B, int K, const int* active, hipStream_t s) {
-    int n = 1;
+// K <= 256 (C3: K = 150): rank sort.  Thread i counts the entries that precede entry i in the (cost, index) order -- K broadcast LDS
+// reads and compares, no barrier after the staging -- and writes order[rank] = i.  (A 36-step bitonic network on 256 slots took 9 us,
+// this takes ~2: a lone wave pays ~8 cycles per instruction whatever it does, so the instruction count is the cost.)
+__global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int m_elite, int* active) {
+    MPOPIS_HI_PRIO();
+    __shared__ __attribute__((aligned(16))) double c[256], sc[256];
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int i = threadIdx.x;
+    const double ci = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+    c[i] = ci;
+    __syncthreads();
+    int rank = 0;
+    const int K4 = (i < K) ? (K & ~3) : 0, Kr = (i < K) ? K : 0;
+    sc[i] = INFINITY;
+    for (int j = 0; j < K4; j += 4) {
+        const double c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
+        rank += ((c0 < ci) || (c0 == ci && j < i)) + ((c1 < ci) || (c1 == ci && j + 1 < i)) + ((c2 < ci) || (c2 == ci && j + 2 < i)) +
+                ((c3 < ci) || (c3 == ci && j + 3 < i));
+    }
+    for (int j = K4; j < Kr; ++j) rank += ((c[j] < ci) || (c[j] == ci && j < i));
+    __syncthreads();
+    if (i < K) { order[(size_t)b * K + rank] = i; sc[rank] = ci; }
+    __syncthreads();
+    elite_break_tail(sc, m_elite, active, b);
+}
+
+// order = sortperm(cost) per slot, and (m_elite >= 2) the elite early-break check on the sorted costs
+void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s) {
+    if (K <= 256) { hipLaunchKernelGGL(k_sortperm_rank, dim3(B), dim3(256), 0, s, cost, order, K, m_elite, active); return; }
+    int n = 512;
     while (n < K) n <<= 1;
     const size_t bytes = (size_t)n * (sizeof(double) + sizeof(int32_t));
-    static std::atomic<unsigned long long> seen{0};
-    ensure_dyn_lds((const void*)k_sortperm, 160 * 1024, seen);
-    hipLaunchKernelGGL(k_sortperm, dim3(B), dim3(n >= 2048 ? 1024 : 256), bytes, s, cost, order, K, n, active);
-}
-
-// CE/CMA early break: if max_j |c[order[j+1]] - c[order[j]]| < 10e-3 over the elite set, the slot
-// leaves the AIS loop (active[b] = 0) -- nothing of this iteration's update is applied.
-__global__ void __launch_bounds__(256) k_elite_break(const double* __restrict__ cost, const int32_t* __restrict__ order, int K, int m_elite,
-                                                     int* active) {
-    MPOPIS_HI_PRIO();
-    const int b = blockIdx.x;
-    if (!active[b]) return;
-    __shared__ double sh[4];
-    double mx = -INFINITY;
-    for (int j = threadIdx.x; j + 1 < m_elite; j += 256)
-        mx = fmax(mx, fabs(cost[(size_t)b * K + order[(size_t)b * K + j + 1]] - cost[(size_t)b * K + order[(size_t)b * K + j]]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-        if (m_elite >= 2 && mx < 10e-3) active[b] = 0;
-    }
-}
-void launch_elite_break(const double* cost, const int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_elite_break, dim3(B), dim3(256), 0, s, cost, order, K, m_elite, active);
+    static std::atomic<unsigned long long> seen8{0};
+    if (n >= 8192) {
+        ensure_dyn_lds((const void*)k_sortperm<8>, 150 * 1024, seen8);
+        hipLaunchKernelGGL(k_sortperm<8>, dim3(B), dim3(n / 8), bytes, s, cost, order, K, n, m_elite, active);
+    } else if (n >= 2048) hipLaunchKernelGGL(k_sortperm<4>, dim3(B), dim3(n / 4), bytes, s, cost, order, K, n, m_elite, active);
+    else hipLaunchKernelGGL(k_sortperm_lds, dim3(B), dim3(n / 2), bytes, s, cost, order, K, n, m_elite, active);
 }
 
 // StatsBase.make_alias_table!(w, 1.0, a, alias): Vose's construction with LIFO stacks of smalls and

@@ -268,3 +268,10 @@ def test_cooperative_cholesky_cs300(eng_mod, track):
         outs.append((got["control"][:2].copy(), got["cost"][:2].copy()))
         eng.close()
     assert np.max(np.abs(outs[0][0] - outs[1][0])) < 1e-9 and rel_err(outs[0][1], outs[1][1]) < 1e-9
+
+
+@pytest.mark.parametrize("K", [100, 300, 8192])
+def test_sortperm_sizes_through_cemppi(eng_mod, oracle, track, K):
+    """order = sortperm(cost) (:455) has three device kernels: rank sort (K <= 256), the all-LDS bitonic network (n = 512, 1024) and the
+    register/shuffle network (n >= 2048; K = 8192: 8 entries per thread).  The elite statistics must match the oracle."""
+    run_case(eng_mod, oracle, track, "cemppi", 1, K, 10, 3, steps=1)
