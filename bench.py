@@ -206,17 +206,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     tm = eng.timing_read()
-    # Outside the timed region: the same workload on ONE stream (mpopis_set_overlap(0)).  In the default schedule the batch runs
-    # as two skewed half-batch chains on two streams, so a kernel's event-to-event duration there includes sharing the chip with
-    # the other chain's kernels; the single-stream pass gives every kernel's duration in isolation (what rocprofv3 --stats of
-    # `MPOPIS_NSPLIT=1 python bench.py` shows) and the per-class breakdown of a step.
-    eng.set_overlap(0)
-    eng.timing_enable(2); eng.timing_reset()
-    ms_single, _ = eng.bench_policy_steps(min(args.steps, 5))
-    tm_iso = eng.timing_read()
+    # Outside the timed region: per-class kernel times of a step (same schedule), and the same workload in the opt-in multi-stream
+    # schedule (mpopis_set_overlap(h, 4): four skewed part-chains on their own streams), reported next to the timed figure.
     eng.timing_enable(True); eng.timing_reset()
     eng.bench_policy_steps(min(args.steps, 5))
     tm_all = eng.timing_read()
+    eng.timing_enable(False)
+    eng.set_overlap(4)
+    eng.bench_policy_steps(2)
+    eng.timing_enable(2); eng.timing_reset()
+    ms_multi, rl_multi = eng.bench_policy_steps(args.steps)
+    tm_multi = eng.timing_read()
     eng.timing_enable(False)
     eng.set_overlap(-1)
 
@@ -248,13 +248,10 @@ def main():
         value = total_rollouts / dt
         r_ms, r_n = tm["rollout"]
         r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
-        per_launch = rollouts / max(r_n, 1)          # rollouts one launch of the kernel processes (half a batch in the 2-stream schedule)
+        per_launch = rollouts / max(r_n, 1)          # rollouts one launch of the kernel processes
         ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
         ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
-        i_ms, i_n = tm_iso["rollout"]
-        i_avg_s = (i_ms / max(i_n, 1)) * 1e-3
-        i_per_launch = B * K
-        i_gbs = i_per_launch * BYTES_PER_ROLLOUT / i_avg_s / 1e9
+        m_ms, m_n = tm_multi["rollout"]
         traffic, valu_busy = None, None
         pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")      # written by tools/pmc_summary.py from separate --pmc passes
         if os.path.exists(pj):
@@ -274,11 +271,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1, 4, false>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "rollouts_per_launch": per_launch, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
-                         "schedule": "timed region = default schedule: %d launch(es) per AIS iteration (the batch runs as skewed part-chains on their own streams); a launch shares the chip with the other chain's sampler / moments / Cholesky kernels, so its duration is not a kernel-in-isolation figure -- see `isolated`" % max(1, round(r_n / (args.steps * N_AIS))),
-                         "isolated": {"what": "same workload, single stream (mpopis_set_overlap(0)), measured right after the timed region: one launch = all %d trials" % B,
-                                      "avg_launch_us": i_avg_s * 1e6, "launches": i_n, "rollouts_per_launch": i_per_launch, "achieved": i_gbs, "frac": i_gbs / HBM_PEAK_GBS,
-                                      "ms_per_step_single_stream": ms_single / max(1, min(args.steps, 5)),
-                                      "traffic": (pm.get("hbm_bytes_per_rollout") * i_per_launch) if traffic is not None else None},
+                         "schedule": "timed region = the engine's default schedule (one stream): %d launch per AIS iteration, all %d trials in one launch, nothing else on the GPU while it runs" % (max(1, round(r_n / (args.steps * N_AIS))), B),
+                         "multi_stream": {"what": "same workload, opt-in schedule mpopis_set_overlap(h, 4) (four part-chains on their own streams), measured right after the timed region; a launch then covers a quarter of the trials and shares the chip with the other chains' kernels, so its duration is not a kernel-in-isolation figure",
+                                          "ms_per_step": ms_multi / args.steps, "value": rl_multi / (ms_multi * 1e-3), "rollout_avg_launch_us": (m_ms / max(m_n, 1)) * 1e3, "rollout_launches": m_n},
                          "binding_resource": "FP64 VALU issue (not HBM, not MFMA); valu_busy_frac from the PMC pass in profiles/",
                          "valu_busy_frac": valu_busy,
                          "fp64_reference_algorithm_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS,

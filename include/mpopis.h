@@ -199,9 +199,8 @@ int  mpopis_gather_summary(mpopis_handle *h, const double *records, int32_t n_lo
 int  mpopis_comm_destroy(mpopis_handle *h);
 
 /* Execution knob.  A handle can split its batch into parts that run as independent chains on their own HIP streams, so that
- * the latency-bound links of one chain (Cholesky, weights) hide under another's rollouts.  Default (on < 0 restores it): two
- * parts when one rollout launch is at least 2048 waves (e.g. 32 trials x K = 4096), a single stream below that.
- * on = 0: always one stream (time kernels in isolation); 1 or 2: always two halves; 3, 4: that many parts.
+ * the latency-bound links of one chain (Cholesky, weights) hide under another's rollouts: worth 1-3 % at >= 64 resident
+ * K = 4096 trials, nothing below.  Default (on <= 0): one stream.  on = 1 or 2: two halves; 3, 4: that many parts.
  * Results do not depend on it (bit-identical per slot). */
 int  mpopis_set_overlap(mpopis_handle *h, int32_t on);
 

@@ -130,7 +130,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
         HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_skew[i], hipEventDisableTiming));
     }
     if (const char* e = getenv("MPOPIS_DEBUG_LAUNCH")) h->debug_launch = atoi(e) != 0;
-    if (const char* e = getenv("MPOPIS_NSPLIT")) { h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e))); h->split_auto = false; }   // experiments (tools/ab)
+    if (const char* e = getenv("MPOPIS_NSPLIT")) { h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e))); h->split_auto = false; h->split_pinned = true; }   // experiments / profiling: pins the schedule, mpopis_set_overlap is then ignored
     h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
     h->as = car ? 2 * cfg->num_cars : 1;
     h->ss = car ? 8 * cfg->num_cars : (cfg->env_kind == MPOPIS_ENV_CARTPOLE ? 4 : 2);
@@ -496,8 +496,9 @@ int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double*
 
 int mpopis_set_overlap(mpopis_handle* h, int32_t on) {
     if (!h) return MPOPIS_ERR_ARG;
-    if (on < 0) { h->nsplit = 2; h->split_auto = true; return MPOPIS_OK; }                   // back to the default policy
-    h->nsplit = on ? std::max(2, std::min((int)mpopis_handle::kMaxSplit, (int)on)) : 1;      // 1: two halves; 2..4: that many parts
+    if (h->split_pinned) return MPOPIS_OK;
+    if (on <= 0) { h->nsplit = 1; h->split_auto = true; return MPOPIS_OK; }                   // the default: one stream
+    h->nsplit = std::max(2, std::min((int)mpopis_handle::kMaxSplit, (int)on));               // 1, 2: two halves; 3, 4: that many parts
     h->split_auto = false;
     return MPOPIS_OK;
 }
@@ -597,17 +598,18 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(alive_gate, 1);
 }
 
-// pol(env) for all slots.  With >= 2 slots the batch is split into nsplit (default 2) parts that run as independent chains on
+// pol(env) for all slots.  Opt-in (mpopis_set_overlap): with >= 2 slots the batch is split into parts that run as independent chains on
 // their own streams, each started one sampler later than the previous: while one part sits in a latency-bound link of its chain
 // (Cholesky: nb workgroups on 256 CUs; weights; the scatter's finish), the other half's rollout / sampler fills the chip.
 // Per-slot results are bit-identical to the single-stream order (every kernel is slot-independent and deterministic).
 int mpopis_handle::policy_step_enqueue(bool injected) {
-    // default policy: split only when the rollout launch fills the chip at least twice over (>= 2 waves per SIMD: 2048 waves of
-    // 64 samples).  Below that every kernel of the chain is latency-bound and two chains only compete for the same critical path
-    // (measured: C4, 8 trials x 3 cars: 11.9 ms single stream, 12.1 ms in two parts; C5, 64 trials: 6.79 -> 6.42 ms).
     const int B0 = B;
-    const long long rollout_waves = (long long)B0 * ((K + 63) / 64) * std::max(1, env.ncars);
-    const int np = (split_auto && rollout_waves < 2048) ? 1 : std::min(nsplit, B0);
+    // Default: ONE stream.  The multi-stream schedule (mpopis_set_overlap(h, 2..4): the batch as skewed part-chains on their own streams)
+    // hides the latency-bound links of one chain under the other chains' throughput kernels; since those links became short
+    // (Cholesky 61 -> 29 us) it is worth 1-3 % at >= 64 K=4096-trials and nothing below (ms per step at 1 / 2 / 3 / 4 parts: 32 trials
+    // 3.87 / 3.76 / 3.84 / 4.19, 64 trials 6.52 / 6.46 / 6.45 / 6.35, 128 trials 12.08 / 11.91 / 11.79 / 11.67), at the price of per-kernel
+    // durations that include time-sharing -- opt-in.
+    const int np = split_auto ? 1 : std::min(nsplit, B0);
     if (np < 2) {
         side_free = (xstream[0] != nullptr);
         const int rc = step_enqueue_view(injected, nullptr, nullptr);

@@ -11,10 +11,11 @@ struct mpopis_handle {
     // (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) run under the other half's throughput-bound kernels
     static constexpr int kMaxSplit = 4;
     hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
+    bool split_pinned = false;   // MPOPIS_NSPLIT set: the schedule is fixed for the process
     bool side_free = false;      // batch not split this step: xstream[0] / ev_fork / ev_join[0] carry the CMA side chain (||L^-1||_F beside sort + elite mean)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {nullptr, nullptr, nullptr}, ev_skew[kMaxSplit - 1] = {nullptr, nullptr, nullptr};
     int nsplit = 2;                                                            // parts the batch is split into (1 = single stream)
-    bool split_auto = true;                                                    // split only when the batch is large enough to be throughput-bound
+    bool split_auto = true;                                                    // default schedule (one stream); false: nsplit parts (mpopis_set_overlap)
     mpopis::EnvDesc env{};
     std::string err;
     std::vector<void*> allocs;

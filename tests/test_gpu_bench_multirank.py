@@ -36,4 +36,5 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
     r = d["roofline"]
     assert r["rollouts_per_launch"] * r["launches"] == 64 * 10 * 4096 * 2          # per-launch accounting matches the schedule
-    assert 0 < r["frac"] < 1 and 0 < r["isolated"]["frac"] < 1
+    assert 0 < r["frac"] < 1 and r["launches"] == 2 * 10                      # default schedule: one launch per AIS iteration, all trials
+    assert r["multi_stream"]["ms_per_step"] > 0 and r["multi_stream"]["rollout_launches"] == 4 * 2 * 10
