@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multi-stream", action="store_true", help="also time the opt-in four-part schedule (mpopis_set_overlap(h, 4)) after the timed region")
     # development aids for exercising the N > 1 control flow on a 1-GPU box (never used by the driver): all ranks on cuda:0 over gloo.
     # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -206,19 +207,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     tm = eng.timing_read()
-    # Outside the timed region: per-class kernel times of a step (same schedule), and the same workload in the opt-in multi-stream
-    # schedule (mpopis_set_overlap(h, 4): four skewed part-chains on their own streams), reported next to the timed figure.
+    # Outside the timed region: per-class kernel times of a step (same schedule) and, with --multi-stream, the same workload in the opt-in
+    # multi-stream schedule (mpopis_set_overlap(h, 4): four skewed part-chains on their own streams), reported next to the timed figure.
     eng.timing_enable(True); eng.timing_reset()
     eng.bench_policy_steps(min(args.steps, 5))
     tm_all = eng.timing_read()
     eng.timing_enable(False)
-    eng.set_overlap(4)
-    eng.bench_policy_steps(2)
-    eng.timing_enable(2); eng.timing_reset()
-    ms_multi, rl_multi = eng.bench_policy_steps(args.steps)
-    tm_multi = eng.timing_read()
-    eng.timing_enable(False)
-    eng.set_overlap(-1)
+    ms_multi = rl_multi = None
+    tm_multi = {"rollout": (0.0, 0)}
+    if args.multi_stream:
+        eng.set_overlap(4)
+        eng.bench_policy_steps(2)
+        eng.timing_enable(2); eng.timing_reset()
+        ms_multi, rl_multi = eng.bench_policy_steps(args.steps)
+        tm_multi = eng.timing_read()
+        eng.timing_enable(False)
+        eng.set_overlap(-1)
 
     # ---- strong scaling: BASELINE configs[4] as written = 64 trials in total, 64/N per GPU (N > 1 only) ------------------
     strong = None
@@ -272,8 +276,9 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "rollouts_per_launch": per_launch, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
                          "schedule": "timed region = the engine's default schedule (one stream): %d launch per AIS iteration, all %d trials in one launch, nothing else on the GPU while it runs" % (max(1, round(r_n / (args.steps * N_AIS))), B),
-                         "multi_stream": {"what": "same workload, opt-in schedule mpopis_set_overlap(h, 4) (four part-chains on their own streams), measured right after the timed region; a launch then covers a quarter of the trials and shares the chip with the other chains' kernels, so its duration is not a kernel-in-isolation figure",
-                                          "ms_per_step": ms_multi / args.steps, "value": rl_multi / (ms_multi * 1e-3), "rollout_avg_launch_us": (m_ms / max(m_n, 1)) * 1e3, "rollout_launches": m_n},
+                         "multi_stream": ({"what": "same workload, opt-in schedule mpopis_set_overlap(h, 4) (four part-chains on their own streams), measured right after the timed region; a launch then covers a quarter of the trials and shares the chip with the other chains' kernels, so its duration is not a kernel-in-isolation figure",
+                                           "ms_per_step": ms_multi / args.steps, "value": rl_multi / (ms_multi * 1e-3), "rollout_avg_launch_us": (m_ms / max(m_n, 1)) * 1e3, "rollout_launches": m_n}
+                                          if ms_multi is not None else "not measured (python bench.py --multi-stream; DESIGN.md section 5 has the same-box A/B: 1-3 % faster steps at >= 64 trials)"),
                          "binding_resource": "FP64 VALU issue (not HBM, not MFMA); valu_busy_frac from the PMC pass in profiles/",
                          "valu_busy_frac": valu_busy,
                          "fp64_reference_algorithm_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS,

@@ -20,7 +20,7 @@ def _free_port():
 def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline"]
+           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--multi-stream"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -37,4 +37,4 @@ def test_bench_two_ranks_on_one_gpu():
     r = d["roofline"]
     assert r["rollouts_per_launch"] * r["launches"] == 64 * 10 * 4096 * 2          # per-launch accounting matches the schedule
     assert 0 < r["frac"] < 1 and r["launches"] == 2 * 10                      # default schedule: one launch per AIS iteration, all trials
-    assert r["multi_stream"]["ms_per_step"] > 0 and r["multi_stream"]["rollout_launches"] == 4 * 2 * 10
+    assert r["multi_stream"]["ms_per_step"] > 0 and r["multi_stream"]["rollout_launches"] == 4 * 2 * 10      # --multi-stream pass

@@ -7,13 +7,10 @@ TAG=${1:-r01}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
-cd "$R" && python bench.py > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
+cd "$R" && python bench.py --multi-stream > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
 head -8 "$O"/prof/bench_kernel_stats.csv | cut -c1-160
-# (the rollout kernel's average in this summary mixes the timed region's 64-trial launches with the 16-trial launches of bench.py's
-#  multi_stream pass; filter the kernel trace on grid size for the timed-region figure -- bench.py's own HIP events do that live)
-export MPOPIS_NSPLIT=1     # PMC passes: pin the single-stream schedule for every pass of bench.py, so that counters and durations describe one kernel at a time
 for P in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
