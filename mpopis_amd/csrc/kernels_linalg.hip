@@ -241,7 +241,7 @@ __device__ __forceinline__ int coop_ld(int rows) { return (rows & 31) ? rows : r
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 
-__global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout, int n, int G,
+__global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout, int n, int G, int S,
                                                              const double* scale, int* status, int* active,
                                                              unsigned long long* flags, unsigned long long epoch) {
     MPOPIS_HI_PRIO();
@@ -252,7 +252,12 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
     if (active && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int npan = (n + kNB - 1) / kNB, npad = npan * kNB;
-    const int nown = (npan - g + G - 1) / G;                       // panels g, g + G, ...
+    // ownership: blocks of S consecutive panels dealt round-robin; own panel q <-> panel (q / S) S G + g S + q % S
+    auto own_panel = [&](int q) { return (q / S) * S * G + g * S + (q % S); };
+    auto owner = [&](int j) { return (j / S) % G; };
+    auto qidx = [&](int j) { return (j / (S * G)) * S + (j % S); };
+    int nown = 0;
+    while (nown < kCoopMaxOwn && own_panel(nown) < npan) ++nown;
     const double* Ab = A + (size_t)b * Astride;
     double* Lb = Lout + (size_t)b * n * n;
     unsigned long long* fl = flags + (size_t)b * npan;
@@ -260,14 +265,14 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
     const unsigned long long ok_val = 2 * epoch;
     if (tid == 0) {
         int off = 0;
-        for (int q = 0; q < nown; ++q) { const int rows = npad - (g + q * G) * kNB; p_off[q] = off; p_ld[q] = coop_ld(rows); off += p_ld[q] * kNB; }
+        for (int q = 0; q < nown; ++q) { const int rows = npad - own_panel(q) * kNB; p_off[q] = off; p_ld[q] = coop_ld(rows); off += p_ld[q] * kNB; }
         sh_fail = 0;
     }
     __syncthreads();
     double* P = smem + p_off[nown - 1] + p_ld[nown - 1] * kNB;      // received panel strip [npad][17]
     // ---- own panels <- lower(sc * A), identity beyond n -----------------------------------------------------------------------
     for (int q = 0; q < nown; ++q) {
-        const int c0 = (g + q * G) * kNB, rows = npad - c0, ld = p_ld[q], cnt = rows * kNB;
+        const int c0 = own_panel(q) * kNB, rows = npad - c0, ld = p_ld[q], cnt = rows * kNB;
         double* W = smem + p_off[q];
         for (int e0 = tid; e0 < cnt; e0 += kCoopThreads * 4) {
             double av[4];
@@ -299,10 +304,23 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
 #pragma unroll
         for (int r = 0; r < 4; ++r) Wc[(r0 - c0 + li) + (lk + 4 * r) * ldc] -= acc[r];
     };
-    // factor the diagonal block of own panel q (= panel c), solve the panel, write it out, publish
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS visibility only: does not wait for the global stores in flight
+    int pending = -1;                                   // own panel whose stores are issued but whose flag is not yet set
+    auto publish = [&](int c) {                         // every wave: its stores have left; then one flag store
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&fl[c], ok_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // factor the diagonal block of own panel q (= panel c), solve the panel, write it out; the flag follows at once when the next panel
+    // belongs to another workgroup, otherwise after this workgroup's next panel update (its stores drain meanwhile)
     auto factor_solve_publish = [&](int q, int c) -> bool {
         double* W = smem + p_off[q];
         const int ld = p_ld[q], c0 = c * kNB, h = npan - c;
+        if (pending >= 0) {                             // the previous panel's stores were issued a whole panel update ago: announce it now, before
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the diagonal block, so that the others work on it while this workgroup factors
+            lds_barrier();
+            if (tid == 0) __hip_atomic_store(&fl[pending], ok_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (wv == 0) {
             const bool bad = diag16_factor(lane, [&](int i, int cc) { return W[i + cc * ld]; }, [&](int i, int cc, double v) { W[i + cc * ld] = v; }, dsh);
             if (bad && lane == 0) sh_fail = 1;
@@ -333,9 +351,9 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(&fl[c], ok_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = -1;
+        if (c + 1 < npan && owner(c + 1) == g) { pending = c; lds_barrier(); }   // solved panel visible in LDS for this workgroup's next update
+        else publish(c);
         // rows 0 .. 16c+15 of these columns: zeros above the diagonal, the factored diagonal block (nobody in the cluster reads them)
         for (int e = tid; e < (c0 + kNB) * kNB; e += kCoopThreads) {
             const int i = e % (c0 + kNB), cl = e / (c0 + kNB);
@@ -378,17 +396,17 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
     };
     if (g == 0 && !factor_solve_publish(0, 0)) return;
     for (int j = 0; j + 1 < npan; ++j) {
-        const bool mine = (j % G) == g;
+        const bool mine = owner(j) == g;
         PROF_MARK(g, j, 0);
         if (!mine && !receive(j)) return;
         PROF_MARK(g, j, 1);
-        const double* src = mine ? smem + p_off[j / G] : P;
-        const int src_ld = mine ? p_ld[j / G] : 0, src_row0 = j * kNB;
-        const bool nxt = ((j + 1) % G) == g;
+        const double* src = mine ? smem + p_off[qidx(j)] : P;
+        const int src_ld = mine ? p_ld[qidx(j)] : 0, src_row0 = j * kNB;
+        const bool nxt = owner(j + 1) == g;
         if (nxt) {
-            const int q = (j + 1) / G, c = j + 1;
+            const int q = qidx(j + 1), c = j + 1;
             for (int ta = c + wv; ta < npan; ta += kCoopWaves) tile_update(smem + p_off[q], p_ld[q], c, ta, src, src_ld, src_row0, !mine);
-            __syncthreads();
+            lds_barrier();
             PROF_MARK(g, j, 2);
             if (!factor_solve_publish(q, c)) return;
             PROF_MARK(g, j, 3);
@@ -396,15 +414,16 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
         // the rest of the owned panels (c > j + 1): tiles dealt to the waves across panels
         int idx = wv;
         for (int q = 0; q < nown; ++q) {
-            const int c = g + q * G;
+            const int c = own_panel(q);
             if (c <= j + 1) continue;
             const int h = npan - c;
             for (; idx < h; idx += kCoopWaves) tile_update(smem + p_off[q], p_ld[q], c, c + idx, src, src_ld, src_row0, !mine);
             idx -= h;
         }
-        __syncthreads();
+        lds_barrier();
         PROF_MARK(g, j, 4);
     }
+    // (pending is never left set: the last panel has no successor, so it is published at once)
 }
 
 size_t potrf_coop_flag_words(int B, int n) { return (size_t)B * ((n + kNB - 1) / kNB); }
@@ -421,21 +440,32 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
         return;
     }
     static const int env_G = [] { const char* e = getenv("MPOPIS_POTRF_G"); return e ? atoi(e) : -1; }();
+    static const int env_S = [] { const char* e = getenv("MPOPIS_POTRF_S"); return e ? atoi(e) : -1; }();
+    // panels per ownership block.  S = 2 halves the hand-offs on the critical path but measured no faster (162 vs 158 us at n = 300): the
+    // per-panel chain is barriers + diagonal block + solve + store drain (~6 of 8.2 us), not the hand-off itself
+    const int S = env_S > 0 ? env_S : 1;
     int G = env_G >= 0 ? env_G : 6;
-    if (G > npan) G = npan;
+    const int nblk = (npan + S - 1) / S;
+    if (G > nblk) G = nblk;
     size_t coop_lds = 0;
+    int nown0 = 0;
     if (G >= 2 && coop_flags && coop_epoch) {
         size_t own = 0;                                           // workgroup 0 owns the tallest panels
-        for (int c = 0; c < npan; c += G) { const int rows = npad - c * kNB; own += (size_t)((rows & 31) ? rows : rows + 16) * kNB; }
+        for (int q = 0;; ++q) {
+            const int c = (q / S) * S * G + (q % S);
+            if (c >= npan) break;
+            const int rows = npad - c * kNB;
+            own += (size_t)((rows & 31) ? rows : rows + 16) * kNB; ++nown0;
+        }
         coop_lds = (own + (size_t)npad * kCoopPS) * sizeof(double);
     }
     // clusters must be co-resident: one workgroup per CU (LDS), keep the grid well below the chip so that kernels of other streams
     // cannot starve a cluster forever (they finish on their own; every wait is bounded anyway)
-    if (coop_lds && coop_lds <= 150 * 1024 && (npan + G - 1) / G <= kCoopMaxOwn && B * G <= 128) {
+    if (coop_lds && coop_lds <= 150 * 1024 && nown0 <= kCoopMaxOwn && B * G <= 128) {
         static std::atomic<unsigned long long> seen3{0};
         ensure_dyn_lds((const void*)k_potrf_coop, 150 * 1024, seen3);
         const unsigned long long epoch = ++*coop_epoch;
-        hipLaunchKernelGGL(k_potrf_coop, dim3(B * G), dim3(kCoopThreads), coop_lds, s, A, Astride, L, n, G, scale, status, active, coop_flags, epoch);
+        hipLaunchKernelGGL(k_potrf_coop, dim3(B * G), dim3(kCoopThreads), coop_lds, s, A, Astride, L, n, G, S, scale, status, active, coop_flags, epoch);
         return;
     }
     const size_t strip = (size_t)n * (kNB + 1) * sizeof(double);                             // panel strip
