@@ -1,0 +1,43 @@
+"""The dense linear algebra kernels (Cholesky: LDS / cooperative / one-workgroup global; triangular-inverse trace; Lanczos inverse square root:
+one workgroup / cooperative) exercised directly, below the policy level, through the C++ harness tools/kbench_linalg.hip: sizes on both sides of
+every kernel-selection threshold, batches that do and do not allow co-resident clusters."""
+import os, re, shutil, subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def harness():
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available to build the harness")
+    from mpopis_amd import build
+    build.build()                                                     # the harness links the library's object files
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "build_kbench_linalg.sh")], capture_output=True, text=True, timeout=600)
+    exe = os.path.join(ROOT, "tools", "kbench_linalg_bin")
+    assert os.path.exists(exe), out.stdout + out.stderr
+    return exe
+
+
+def _num(pattern, text):
+    m = re.search(pattern, text)
+    assert m, (pattern, text)
+    return float(m.group(1))
+
+
+@pytest.mark.parametrize("B,n", [(3, 16), (4, 37), (2, 100), (64, 100), (2, 128),          # k_potrf_lds
+                                 (3, 129), (2, 145), (4, 200), (8, 300), (2, 333), (2, 384),   # k_potrf_coop, cooperative Lanczos from n = 160
+                                 (24, 300), (2, 400)])                                        # k_potrf_global (grid too large / LDS too small for clusters)
+def test_linalg_kernels(harness, B, n):
+    r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t = r.stdout
+    assert _num(r"potrf status min (-?\d+)", t) == 0
+    assert _num(r"potrf max \|LL'-A\| = ([0-9.e+-]+)", t) < 1e-14              # entries of A are O(0.1)
+    assert _num(r"max \|upper\| = ([0-9.e+-]+)", t) == 0.0
+    assert _num(r"trtri_fro: .* rel ([0-9.e+-]+)", t) < 1e-11
+    ymax = _num(r"\(\|y\| max ([0-9.e+-]+)\)", t)
+    assert _num(r"lanczos coop vs single: max \|dy\| = ([0-9.e+-]+)", t) < 1e-11 * ymax
+    assert _num(r"invsqrt applied twice: .* = ([0-9.e+-]+)", t) < 1e-9
+    assert _num(r"status (-?\d+), tr", t) == 0

@@ -95,6 +95,27 @@ int main(int argc, char** argv) {
         double d = 0, nr = 0; for (size_t i = 0; i < y0.size(); ++i) { d = fmax(d, fabs(y1[i] - y0[i])); nr = fmax(nr, fabs(y0[i])); }
         printf("   lanczos coop vs single: max |dy| = %.3e (|y| max %.3e)\n", d, nr);
     }
+    {   // applying the operator twice must invert A: y2 = A^-1/2 (A^-1/2 b) = A^-1 b  ->  ||A y2 - b|| / ||b||
+        double* dy2; CK(hipMalloc(&dy2, (size_t)B * n * 8));
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
+        launch_lanczos_invsqrt(dA, nullptr, dy, n, dpart, dV, dy2, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
+        CK(hipStreamSynchronize(s));
+        std::vector<double> y2((size_t)B * n); CK(hipMemcpy(y2.data(), dy2, y2.size() * 8, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int bb = 0; bb < B; ++bb) {
+            double r2 = 0, b2 = 0;
+            for (int i = 0; i < n; ++i) { double v = 0; for (int j = 0; j < n; ++j) v += A[bb * nn + i + (size_t)j * n] * y2[(size_t)bb * n + j]; v -= bv[(size_t)bb * n + i]; r2 += v * v; b2 += bv[(size_t)bb * n + i] * bv[(size_t)bb * n + i]; }
+            worst = fmax(worst, sqrt(r2 / b2));
+        }
+        printf("   invsqrt applied twice: max ||A y2 - b|| / ||b|| = %.3e\n", worst);
+        // tr(A^-1) from the triangular inverse against the host value from L (forward substitution on the identity)
+        std::vector<double> L0(nn); CK(hipMemcpy(L0.data(), dL, nn * 8, hipMemcpyDeviceToHost));
+        double tr = 0; std::vector<double> x(n);
+        for (int c = 0; c < n; ++c) { for (int i = 0; i < n; ++i) { double v = (i == c) ? 1.0 : 0.0; for (int k = c; k < i; ++k) v -= L0[i + (size_t)k * n] * x[k]; x[i] = (i < c) ? 0.0 : v / L0[i + (size_t)i * n]; } for (int i = c; i < n; ++i) tr += x[i] * x[i]; }
+        const int np = (n + 15) / 16; std::vector<double> pp(np); CK(hipMemcpy(pp.data(), dpart, np * 8, hipMemcpyDeviceToHost));
+        double trd = 0; for (double v : pp) trd += v;
+        printf("   trtri_fro: ||L^-1||_F^2 device %.12e host %.12e rel %.2e\n", trd, tr, fabs(trd - tr) / tr);
+    }
     std::vector<int> m(B), st(B); std::vector<double> fro(B);
     CK(hipMemcpy(m.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fro.data(), dfro, B * 8, hipMemcpyDeviceToHost));
     printf("   Lanczos steps m = %d %d ..., status %d, tr(A^-1) = %.6e\n", m[0], m[B > 1 ? 1 : 0], st[0], fro[0]);
