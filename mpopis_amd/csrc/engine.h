@@ -143,7 +143,7 @@ void launch_gather_mean_strided(const double* X, const int32_t* idx, const doubl
 
 // kernels_select.hip
 void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s);   // + elite early break
-void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s);
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws = nullptr);
 void launch_alias_sample(const double* accept, const int32_t* alias, const int32_t* di, size_t di_stride, const double* du,
                          int32_t* out, int32_t* log, size_t log_stride, int B, int K, const int* active, hipStream_t s);
 

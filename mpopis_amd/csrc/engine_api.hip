@@ -160,7 +160,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
     rc |= dalloc(h, &h->d_seeds, B);
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
-    rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K);
+    rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
     h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));   // ~2-4 workgroups per CU in the scatter kernel
     rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
@@ -590,7 +590,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
     mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_seeds, 1);
     mv(d_order, K); mv(d_resi, K); mv(d_alias, K); mv(d_residx_log, (ptrdiff_t)std::max(1, N - 1) * K); mv(d_resi_in, (ptrdiff_t)(N - 1) * K);
-    mv(d_resu, K); mv(d_accept, K); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
+    mv(d_resu, K); mv(d_accept, K); mv(d_alias_need, 1); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
     mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
     mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs, lan_regions)); mv(d_lan_x, (ptrdiff_t)invsqrt_coop_words(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_fro, 1); mv(d_lan_m, 1);

@@ -45,6 +45,7 @@ struct mpopis_handle {
     double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
     unsigned long long* d_coop_flags = nullptr; unsigned long long coop_epoch = 0;         // cooperative Cholesky (cs > 128): panel flags [B][ceil(cs/16)], launch counter
     unsigned long long* d_lan_x = nullptr; int lan_regions = 1;                            // cooperative Lanczos: exchange granules, basis spill regions per slot
+    int* d_alias_need = nullptr;                                                           // :pmcmppi: slots whose alias table the parallel construction could not certify
     int* d_lan_m = nullptr;                                                                // Lanczos steps taken per slot (diagnostic)
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
     // Level-3 harness

@@ -170,7 +170,7 @@ void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_eli
 // larges, executed in the reference's exact operation order (the result must be bit-identical for
 // identical w).  The wave classifies with ballots (keeps index order), then runs the pairing loop (see below).
 __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
-                                                    int K, const int* active) {
+                                                    int K, const int* active, const int* need) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* a = reinterpret_cast<double*>(smem);
@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
     int32_t* smalls = larges + K;
     const int b = blockIdx.x;
     if (active && !active[b]) return;
+    if (need && !need[b]) return;                               // the parallel construction was certain of every decision
     const int lane = threadIdx.x;
     const double ac = (double)K / 1.0;                          // n / wsum
     int kl = 0, ks = 0;
@@ -256,11 +257,130 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
     __syncthreads();
     for (int i = lane; i < K; i += 64) { accept[(size_t)b * K + i] = a[i]; alias[(size_t)b * K + i] = al[i]; }
 }
-void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// The same table without the sequential loop.  What the LIFO discipline of make_alias_table! does, in cumulative terms: pop
+// order = descending index; with e_i = a - 1 of the i-th popped large, d_j = 1 - a of the j-th popped small and their prefix sums
+// E_i, D_j, the large in charge when small j is popped is the first one whose cumulative capacity exceeds the deficits absorbed so
+// far, i(j) = min{i : E_i > D_{j-1}}; large i is exhausted by the first small m with D_m >= E_i, lands on the smalls stack with
+// a = 1 - (D_m - E_i) and is absorbed by large i+1 (alias[L_i] = L_{i+1}); smalls left over when the larges run out, the last
+// exhausted large and entries with a == 1 end with a = 1 and alias = self; a large that is never exhausted keeps a = 1 + (E_i - D_last).
+// That is two prefix scans and one binary search per entry instead of K dependent steps (420 us at K = 4096).
+// Exactness: alias[] is index work and must equal the sequential result.  The sequential partial sums differ from the scanned ones
+// only by rounding (<= 2K operations of magnitude <= K: 4 K^2 eps), so every decision whose margin exceeds that bound is the
+// sequential decision; if ANY comparison of a slot is closer than the bound (exact ties included), the slot is flagged and the
+// sequential kernel redoes it.  accept[] of exhausted / partly used larges is 1 - (D - E) from the scans instead of the
+// sequentially rounded chain: a floating-point deviation of <= 4 K^2 eps (typically 1e-13); all other entries are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int kAliasParThreads = 1024;
+__global__ void __launch_bounds__(kAliasParThreads) k_alias_build_par(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
+                                                                      int K, const int* active, int* need) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* pre = reinterpret_cast<double*>(smem);              // E_0 .. E_{nL-1} from the front, D_0 .. D_{nS-1} from the back (pre[K-1-j])
+    int32_t* Lidx = reinterpret_cast<int32_t*>(smem + (size_t)K * 8);
+    __shared__ double wsE[16], wsD[16];
+    __shared__ int wcL[16], wcS[16], sh_unsafe;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double ac = (double)K / 1.0;
+    constexpr int EPT = 8;                                      // K <= 8192
+    const int per = (K + kAliasParThreads - 1) / kAliasParThreads;             // entries per thread, consecutive in pop order (descending index)
+    double av[EPT];
+    double sE = 0.0, sD = 0.0; int cL = 0, cS = 0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int r = tid * per + u;                            // pop-order position
+        av[u] = 1.0;
+        if (u < per && r < K) {
+            av[u] = w[(size_t)b * K + (K - 1 - r)] * ac;
+            if (av[u] > 1.0) { sE += av[u] - 1.0; ++cL; } else if (av[u] < 1.0) { sD += 1.0 - av[u]; ++cS; }
+        }
+    }
+    if (tid == 0) sh_unsafe = 0;
+    // exclusive block scans of (sE, sD, cL, cS) over the threads
+    double xE = sE, xD = sD; int xL = cL, xS = cS;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double tE = __shfl_up(xE, o, 64), tD = __shfl_up(xD, o, 64); const int tL = __shfl_up(xL, o, 64), tS = __shfl_up(xS, o, 64);
+        if (lane >= o) { xE += tE; xD += tD; xL += tL; xS += tS; }
+    }
+    if (lane == 63) { wsE[wv] = xE; wsD[wv] = xD; wcL[wv] = xL; wcS[wv] = xS; }
+    __syncthreads();
+    double oE = 0.0, oD = 0.0; int oL = 0, oS = 0, nL = 0, nS = 0;
+    for (int q = 0; q < kAliasParThreads / 64; ++q) {
+        if (q < wv) { oE += wsE[q]; oD += wsD[q]; oL += wcL[q]; oS += wcS[q]; }
+        nL += wcL[q]; nS += wcS[q];
+    }
+    double runE = oE + (xE - sE), runD = oD + (xD - sD);        // exclusive prefixes of this thread
+    int rL = oL + (xL - cL), rS = oS + (xS - cS);
+    const int myL0 = rL, myS0 = rS;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        if (av[u] > 1.0) { runE += av[u] - 1.0; pre[rL] = runE; Lidx[rL] = K - 1 - (tid * per + u); ++rL; }
+        else if (av[u] < 1.0) { runD += 1.0 - av[u]; pre[K - 1 - rS] = runD; ++rS; }
+    }
+    __syncthreads();
+    const double tol = fmax(4.0 * (double)K * (double)K * 2.220446049250313e-16, 1e-12);
+    auto Eat = [&](int i) { return pre[i]; };
+    auto Dat = [&](int j) { return pre[K - 1 - j]; };
+    const double Dtot = (nS > 0) ? Dat(nS - 1) : 0.0;            // all deficits, as the scan accumulated them
+    int unsafe = 0;
+    rL = myL0; rS = myS0;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int r = tid * per + u;
+        if (!(u < per && r < K)) continue;
+        const int i = K - 1 - r;
+        double acc = 1.0; int al = i;
+        if (av[u] < 1.0) {                                      // small number rS of the pop order
+            const double lo = (rS > 0) ? Dat(rS - 1) : 0.0;
+            int a0 = 0, a1 = nL;                                // first i with E_i > lo
+            while (a0 < a1) { const int mid = (a0 + a1) >> 1; if (Eat(mid) > lo) a1 = mid; else a0 = mid + 1; }
+            if (a0 < nL) { acc = av[u]; al = Lidx[a0]; if (!(Eat(a0) - lo > tol)) unsafe |= 1; }
+            if (a0 > 0 && !(lo - Eat(a0 - 1) > tol)) unsafe |= 2;
+            ++rS;
+        } else if (av[u] > 1.0) {                               // large number rL
+            const double Ei = Eat(rL), Ep = (rL > 0) ? Eat(rL - 1) : 0.0;
+            int a0 = 0, a1 = nS;                                // first m with D_m >= E_i
+            while (a0 < a1) { const int mid = (a0 + a1) >> 1; if (Dat(mid) >= Ei) a1 = mid; else a0 = mid + 1; }
+            // The weights sum to 1, so total excess = total deficit in exact arithmetic: the LAST large meets the last small in an exact tie
+            // that rounding decides either way -- harmlessly: nothing is popped after it, its alias stays itself and its acceptance is 1 (or
+            // 1 + 1e-13: "always accept" both ways).  Its own comparisons are therefore exempt from the margin test (a small whose
+            // pairing depends on that tie is still caught by its own test).
+            const bool last = (rL + 1 == nL);
+            if (a0 < nS) {                                      // exhausted by small a0
+                if (!last && !(Dat(a0) - Ei > tol)) unsafe |= 4;
+                if (!last) { acc = 1.0 - (Dat(a0) - Ei); al = Lidx[rL + 1]; }                  // absorbed by the next large; the last one ends at 1.0
+            } else {
+                if (!last && !(Ei - Dtot > tol)) unsafe |= 8;
+                acc = (Dtot > Ep) ? fmax(1.0, 1.0 + (Ei - Dtot)) : av[u];                      // partly used / untouched: still a large
+            }
+            if (!last && a0 > 0 && !(Ei - Dat(a0 - 1) > tol)) unsafe |= 16;
+            ++rL;
+        }
+        accept[(size_t)b * K + i] = acc;
+        alias[(size_t)b * K + i] = al;
+    }
+    if (unsafe) atomicOr(&sh_unsafe, unsafe);
+    __syncthreads();
+    if (tid == 0) need[b] = sh_unsafe;
+}
+
+// need_ws (nullable): B ints of workspace; with it the parallel construction runs first and the sequential kernel only redoes the slots
+// that the parallel one could not certify
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws) {
     const size_t bytes = (size_t)K * (8 + 4 + 4 + 4);
-    static std::atomic<unsigned long long> seen{0};
+    static std::atomic<unsigned long long> seen{0}, seenp{0};
+    static const int env_par = [] { const char* e = getenv("MPOPIS_ALIAS_PAR"); return e ? atoi(e) : 1; }();
+    const bool par = need_ws && env_par && K <= 8192;
+    if (par) {
+        ensure_dyn_lds((const void*)k_alias_build_par, 150 * 1024, seenp);
+        hipLaunchKernelGGL(k_alias_build_par, dim3(B), dim3(kAliasParThreads), (size_t)K * 12, s, w, accept, alias, K, active, need_ws);
+        if (getenv("MPOPIS_ALIAS_DEBUG")) { std::vector<int> nd(B); (void)hipStreamSynchronize(s); (void)hipMemcpy(nd.data(), need_ws, B * 4, hipMemcpyDeviceToHost); fprintf(stderr, "alias need:"); for (int v : nd) fprintf(stderr, " %d", v); fprintf(stderr, "\n"); }
+    }
     ensure_dyn_lds((const void*)k_alias_build, 160 * 1024, seen);
-    hipLaunchKernelGGL(k_alias_build, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active);
+    hipLaunchKernelGGL(k_alias_build, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active, par ? (const int*)need_ws : (const int*)nullptr);
 }
 
 // rand(rng, s::AliasTable): i = rand(1:n); u = rand(); u < accept[i] ? i : alias[i]

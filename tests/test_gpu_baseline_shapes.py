@@ -13,6 +13,7 @@ Tolerances: BASELINE.json asks 1e-5 relative on control / per-step cost; held to
 controls absolute on [-1,1] actions), integers (iterations, resampling indices) bit-exact.  Σ′ is compared
 relative to its largest diagonal entry.
 """
+import os
 import numpy as np
 import pytest
 
@@ -275,3 +276,26 @@ def test_sortperm_sizes_through_cemppi(eng_mod, oracle, track, K):
     """order = sortperm(cost) (:455) has three device kernels: rank sort (K <= 256), the all-LDS bitonic network (n = 512, 1024) and the
     register/shuffle network (n >= 2048; K = 8192: 8 entries per thread).  The elite statistics must match the oracle."""
     run_case(eng_mod, oracle, track, "cemppi", 1, K, 10, 3, steps=1)
+
+
+@pytest.mark.parametrize("K,groups", [(256, 2), (256, 4), (1000, 2), (4096, 3), (4096, 0), (150, 0)])
+def test_pmcmppi_alias_table_parallel_equals_sequential(tmp_path, K, groups):
+    """:pmcmppi builds the alias table (:804, StatsBase.make_alias_table!) with prefix scans instead of the sequential pairing loop and
+    certifies every pairing decision by its margin; slots with a decision too close to call are redone by the sequential kernel (the
+    reference's operations in the reference's order).  With only a few DISTINCT noise columns the weights take a few distinct values in
+    equal-sized groups and the excess / deficit prefix sums tie (almost) exactly all along the table -- the worst case for the
+    certification, and one where the reference's own result hinges on the last bit of the weights, so the comparison is device
+    (parallel + fall-back) against device (sequential only, MPOPIS_ALIAS_PAR=0) on identical weights: indices must be identical.
+    groups = 0: generic weights (everything certified)."""
+    import subprocess, sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "alias_ab_worker.py")
+    outs = []
+    for par in ("1", "0"):
+        f = str(tmp_path / ("alias_%s.npz" % par))
+        env = dict(os.environ, MPOPIS_ALIAS_PAR=par)
+        r = subprocess.run([sys.executable, worker, str(K), str(groups), f], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(f))
+    a, b = outs
+    assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["res"], b["res"])
+    assert np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["control"], b["control"])

@@ -1,5 +1,8 @@
 """Randomised engine-vs-oracle parity sweep (dev tool; the committed tests hold fixed cases).  Random policy / cars / K / T / N / B,
-random start states, injected or device noise, random multi-stream split.  usage: python tools/fuzz_parity.py <n_cases> <seed>"""
+random start states, injected or device noise, random multi-stream split.  usage: python tools/fuzz_parity.py <n_cases> <seed>
+A few costs per case may differ beyond 1e-7 without being a bug: rollouts that brake to a standstill chatter; the sweep
+allows ncars*K/200 of them per slot as long as control and U agree to 1e-6 (the committed tests identify those rollouts from the oracle's
+own trajectory instead)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -74,7 +77,7 @@ for case in range(ncases):
             rel = np.abs(got["cost"][b] - r["cost"]) / (np.abs(r["cost"]) + 1e-9)
             nbad = int((rel > 1e-7).sum())
             ea = float(np.abs(got["control"][b] - r["control"]).max()); eu = float(np.abs(U[b] - pols[b].U).max())
-            if got["iters_run"][b] != r["iters_run"] or nbad > max(2, K // 200) or ea > 1e-6 or eu > 1e-6:
+            if got["iters_run"][b] != r["iters_run"] or nbad > max(2, ncars * K // 200) or ea > 1e-6 or eu > 1e-6:
                 print("FAIL", tag, "step", step, "slot", b, "iters", got["iters_run"][b], r["iters_run"], "cost-bad", nbad, "max rel %.2e" % rel.max(), "ctrl %.2e U %.2e" % (ea, eu))
                 ok = False
         if not ok:
