@@ -123,6 +123,7 @@ void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
 // kernels_mfma.hip
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
+bool sample_trmm_fusable(int n);
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);

@@ -653,6 +653,14 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     copy_f64(d_U, d_Ucur, (size_t)B * cs, stream);
     if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
     if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
+    // Shapes the fused sampler does not cover (cs > 128: Z goes through memory anyway) with device RNG, a dense proposal from iteration 2 on
+    // and the handle's other streams free: prefetch Z on a side stream (see below).  For fusable shapes the prefetch was measured and LOSES
+    // (C5, 64 trials: 6.72 vs 6.45 ms per step: the drawing then competes with the moments kernel instead of filling the MFMA bubbles of
+    // the fused kernel); MPOPIS_ZPREFETCH=2 forces it for such A/B runs, 0 disables it.
+    static const int env_zpre = [] { const char* e = getenv("MPOPIS_ZPREFETCH"); return e ? atoi(e) : 1; }();
+    const bool z_prefetch_ok = env_zpre && (env_zpre == 2 || !sample_trmm_fusable(cs)) && side_free && xstream[1] && !injected && pol != MPOPIS_POL_MPPI &&
+                               !(sigma_diag && sigma_fixed) && N > 1;
+    bool z_prefetched = false;
     for (int n = 1; n <= N; ++n) {
         // ---- P = MvNormal(Σ′): Cholesky; Σ_inv only through gvec --------------------------------
         const double* Lp; size_t Lstride; const double* dsc = nullptr;
@@ -679,6 +687,11 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             if (pol == MPOPIS_POL_MPPI) launch_mppi_Z_in(d_Zin, Zdst, B, T, K, as, stream);       // N == 1
             else launch_transpose_in(d_Zin + (size_t)(n - 1) * per, Zdst, B, cs, K, stream, (size_t)N * per);
             if (dsc) launch_scale_rows(Zdst, dsc, B, cs, K, stream);
+        } else if (z_prefetched) {
+            // this iteration's standard normals were drawn on the side stream while the previous iteration's reweighting / moments / Cholesky
+            // kernels (a few workgroups each) left the chip idle: only the matrix product is left on the critical path
+            (void)hipStreamWaitEvent(stream, ev_skew[1], 0);
+            z_prefetched = false;
         } else if (!dsc && pol != MPOPIS_POL_MPPI) {
             // dense proposal: draw inside the unwhitening kernel when the shape allows it (no Z round trip through HBM)
             fused = launch_sample_trmm_fused(Lp, Lstride, d_E, B, cs, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), d_active, stream);
@@ -691,6 +704,14 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         if (n == 1 && record_after_first_sampler) (void)hipEventRecord(record_after_first_sampler, stream);   // the next part starts when this one enters its first rollout
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active, d_iters, n);   // also records iters_run = n for the active slots
+        if (z_prefetch_ok && n < N) {
+            // Z of iteration n+1 depends on nothing but (seed, MPC step, iteration): draw it now, beside the latency-bound kernels that follow
+            (void)hipEventRecord(ev_skew[0], stream);
+            (void)hipStreamWaitEvent(xstream[1], ev_skew[0], 0);
+            launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, d_active, xstream[1]);
+            (void)hipEventRecord(ev_skew[1], xstream[1]);
+            z_prefetched = true;
+        }
         // ---- adapt (μ, Σ′) ----------------------------------------------------------------------
         if (n < N) {
             int rc = ais_update(n, injected);

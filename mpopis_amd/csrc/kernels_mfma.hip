@@ -124,10 +124,10 @@ void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, doubl
                        RngArgs{nullptr, 0, 0});
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
+bool sample_trmm_fusable(int n) { return !(n & 1) && (n + 15) / 16 <= kTrmmTiles; }
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s) {
-    const int nt = (n + 15) / 16;
-    if ((n & 1) || nt > kTrmmTiles) return false;
+    if (!sample_trmm_fusable(n)) return false;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
                        RngArgs{seeds, slo, shi});
     return true;
