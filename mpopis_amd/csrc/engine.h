@@ -84,6 +84,8 @@ struct RolloutArgs {
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
 void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s);
+void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
+                       const double* x, double* xext, int ncars, hipStream_t st);
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,

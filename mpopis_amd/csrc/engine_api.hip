@@ -643,14 +643,9 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     if (wait_first) (void)hipStreamWaitEvent(stream, wait_first, 0);
     const size_t nn = (size_t)cs * cs, per = (size_t)cs * K;
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
-    if (!status_sticky) fill_i32(d_status, 0, B, stream);
-    if (alive_gate) (void)hipMemcpyAsync(d_active, alive_gate, sizeof(int) * B, hipMemcpyDeviceToDevice, stream);   // frozen trials stay out
-    else fill_i32(d_active, 1, B, stream);
-    fill_i32(d_iters, 0, B, stream);
-    prepare_state();
-    // U_orig = pol.U  (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop)
-    copy_f64(d_U, d_Uin, (size_t)B * cs, stream);
-    copy_f64(d_U, d_Ucur, (size_t)B * cs, stream);
+    // status / active / iters reset, U_orig = pol.U (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop), extended start states
+    launch_step_begin(status_sticky ? nullptr : d_status, d_active, alive_gate, d_iters, d_U, d_Uin, d_Ucur, B, cs,
+                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream);
     if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
     if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
     // Shapes the fused sampler does not cover (cs > 128: Z goes through memory anyway) with device RNG, a dense proposal from iteration 2 on

@@ -166,6 +166,28 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
     hipLaunchKernelGGL(k_extend_state, dim3((n + 63) / 64), dim3(64), 0, st, x, xext, n);
 }
 
+// Start of an MPC step, one launch instead of seven (at one trial the step is a chain of dependent launches, each boundary costs 2-4 us):
+// status = 0 (unless sticky), active = alive gate (or 1), iters = 0, U_orig = the loop's pol.U = pol.U, and the car start states extended
+// with sin/cos of psi / delta (as k_extend_state).
+__global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur,
+                                                    int cs, const double* x, double* xext, int ncars) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; }
+    for (int i = tid; i < cs; i += 256) { const double u = U[(size_t)b * cs + i]; Uin[(size_t)b * cs + i] = u; Ucur[(size_t)b * cs + i] = u; }
+    if (x && tid < ncars) {
+        const size_t i = (size_t)b * ncars + tid;
+        CarState c;
+        car_state_from8(c, x + i * 8);
+        double* o = xext + i * kCarExt;
+        o[0] = c.x; o[1] = c.y; o[2] = c.psi; o[3] = c.Vx; o[4] = c.Vy; o[5] = c.r; o[6] = c.delta; o[7] = c.pedal;
+        o[8] = c.sp; o[9] = c.cp; o[10] = c.sd; o[11] = c.cd;
+    }
+}
+void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
+                       const double* x, double* xext, int ncars, hipStream_t st) {
+    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars);
+}
+
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
         hipLaunchKernelGGL(k_rollout_simple<2>, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
