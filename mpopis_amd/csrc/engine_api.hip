@@ -28,6 +28,7 @@ static std::string g_create_error;
     } while (0)
 
 #include "engine_handle.h"
+#include <chrono>
 
 // ---- tiny utility kernels -----------------------------------------------------------------------
 __global__ void k_fill_i32(int* p, int v, size_t n) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = v; }
@@ -73,9 +74,22 @@ void mpopis_handle::time_end() {
     ev_open = false;
 }
 
+// Host wait for the handle's stream.  A synchronous pol(env) of one trial is 0.2-2 ms of GPU work; hipStreamSynchronize's blocking wake-up
+// adds 20-50 us to that, so poll the stream for the first 3 ms (one host thread spinning, as a CPU implementation of the call would) and
+// only then block.
+static hipError_t wait_stream(hipStream_t s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+    }
+    return hipStreamSynchronize(s);
+}
+
 static int sync_status(mpopis_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     int st = 0;
     for (int b = 0; b < h->B; ++b) st = std::min(st, h->h_status[b]);
     if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
@@ -245,7 +259,7 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     if (dalloc(h, &dnd, nd.size()) || dalloc(h, &dni, ni.size())) return MPOPIS_ERR_HIP;
     HIPCHK(h, hipMemcpyAsync(dnd, nd.data(), sizeof(double) * nd.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dni, ni.data(), sizeof(int) * ni.size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P, dni, dnd, W};
     return MPOPIS_OK;
 }
@@ -281,7 +295,7 @@ int mpopis_set_state(mpopis_handle* h, const double* x, const int32_t* t, const 
     HIPCHK(h, hipMemcpyAsync(h->d_x, x, sizeof(double) * h->B * h->ss, hipMemcpyHostToDevice, h->stream));
     if (t) HIPCHK(h, hipMemcpyAsync(h->d_t, t, sizeof(int) * h->B, hipMemcpyHostToDevice, h->stream));
     if (done) HIPCHK(h, hipMemcpyAsync(h->d_done, done, sizeof(int) * h->B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -291,7 +305,7 @@ int mpopis_get_state(mpopis_handle* h, double* x, int32_t* t, int32_t* done) {
     if (x) HIPCHK(h, hipMemcpyAsync(x, h->d_x, sizeof(double) * h->B * h->ss, hipMemcpyDeviceToHost, h->stream));
     if (t) HIPCHK(h, hipMemcpyAsync(t, h->d_t, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
     if (done) HIPCHK(h, hipMemcpyAsync(done, h->d_done, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -299,14 +313,14 @@ int mpopis_set_U(mpopis_handle* h, const double* U) {
     if (!h || !U) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_U, U, sizeof(double) * h->B * h->cs, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 int mpopis_get_U(mpopis_handle* h, double* U) {
     if (!h || !U) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(U, h->d_U, sizeof(double) * h->B * h->cs, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -336,7 +350,7 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     fill_i32(h->d_status, 0, h->B, h->stream);
     launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->d_coop_flags, &h->coop_epoch);
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     if (h->h_status[0] != 0) { h->err = "PosDefException: Sigma is not positive definite"; return MPOPIS_ERR_NOT_PD; }
     return MPOPIS_OK;
 }
@@ -347,7 +361,7 @@ int mpopis_seed(mpopis_handle* h, uint64_t seed) {
     for (int b = 0; b < h->B; ++b) s[b] = seed + (uint64_t)b + 1;              // seed!(pol, seed + k), car_example.jl:188
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_seeds, s.data(), sizeof(uint64_t) * h->B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     h->mpc_step = 0;
     return MPOPIS_OK;
 }
@@ -356,7 +370,7 @@ int mpopis_seed_slots(mpopis_handle* h, const uint64_t* seeds) {
     if (!h || !seeds) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * h->B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     h->mpc_step = 0;
     return MPOPIS_OK;
 }
@@ -373,7 +387,7 @@ int mpopis_get_Sigma(mpopis_handle* h, double* out) {
     hipLaunchKernelGGL(k_scaled_copy_f64, dim3((nn + 255) / 256, h->B), dim3(256), 0, h->stream,
                        sigma_fixed ? h->d_Sigma0 : h->d_Sig, sigma_fixed ? (size_t)0 : nn, scale, h->d_tmpS, nn);
     HIPCHK(h, hipMemcpyAsync(out, h->d_tmpS, sizeof(double) * h->B * nn, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -399,7 +413,7 @@ int mpopis_rollout_costs(mpopis_handle* h, const double* x0, const double* U, co
     h->prepare_state();
     h->rollout(h->d_Ucur, h->d_Uin, gv, nullptr);
     HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     HIPCHK(h, hipGetLastError());
     return MPOPIS_OK;
 }
@@ -426,7 +440,7 @@ int mpopis_env_query(mpopis_handle* h, double* reward, int32_t* within, double* 
     if (within) HIPCHK(h, hipMemcpyAsync(within, h->d_qwithin, sizeof(int) * B, hipMemcpyDeviceToHost, h->stream));
     if (dist) HIPCHK(h, hipMemcpyAsync(dist, h->d_qdist, sizeof(double) * B * NC, hipMemcpyDeviceToHost, h->stream));
     if (beta) HIPCHK(h, hipMemcpyAsync(beta, h->d_qbeta, sizeof(double) * B * NC, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -435,7 +449,7 @@ int mpopis_get_trajectories(mpopis_handle* h, double* out) {
     if (!h->d_traj) { h->err = "log_trajectories was not enabled"; return MPOPIS_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(out, h->d_traj, sizeof(double) * h->B * h->K * h->T * h->ss, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     return MPOPIS_OK;
 }
 
@@ -518,7 +532,7 @@ int mpopis_timing_reset(mpopis_handle* h) { if (!h) return MPOPIS_ERR_ARG; h->ev
 int mpopis_timing_read(mpopis_handle* h, char* names, int32_t names_cap, double* ms_total, int64_t* launches, int32_t* n) {
     if (!h || !n) return MPOPIS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     const char* const* kNames = kClassNames;
     const int nslots = 7;
     std::vector<double> ms(nslots, 0.0); std::vector<int64_t> cnt(nslots, 0);
@@ -540,7 +554,7 @@ int mpopis_bench_policy_steps(mpopis_handle* h, int32_t steps, double* ms, doubl
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, wait_stream(h->stream));
     HIPCHK(h, hipEventRecord(e0, h->stream));
     double rl = 0.0;
     for (int s = 0; s < steps; ++s) {
