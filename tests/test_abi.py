@@ -73,3 +73,21 @@ def test_product_never_imports_oracle():
     from mpopis_amd import _lib
     out = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_header_is_plain_c_and_a_c_program_links(L, tmp_path):
+    """include/mpopis.h is the drop-in boundary: it must be consumable by a plain C99 compiler (no C++, no torch, no HIP types in the
+    signatures) and a C program must link against the shared library with nothing but -lmpopis_hip."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = os.path.join(ROOT, "tests", "abi_client.c")
+    inc = os.path.join(ROOT, "include")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + inc, "-fsyntax-only", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    libdir = os.path.join(ROOT, "mpopis_amd", "lib")
+    exe = str(tmp_path / "abi_client")
+    r = subprocess.run(["gcc", "-std=c99", "-I" + inc, src, "-L" + libdir, "-lmpopis_hip", "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    hdr = open(os.path.join(inc, "mpopis.h")).read()
+    assert "torch" not in hdr and "hip/" not in hdr and "std::" not in hdr

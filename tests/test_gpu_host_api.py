@@ -182,3 +182,33 @@ def test_debug_launch_checks_and_two_handles_one_device(M, monkeypatch):
     assert np.all(np.isfinite(rc_["control"]))
     for e in (a, b, c):
         e.close()
+
+
+def test_plain_c_client_gives_the_same_numbers_as_the_python_mirror(M, tmp_path):
+    """tests/abi_client.c (C99, links only libmpopis_hip.so) runs a MountainCar :cemppi closed loop on the device RNG; the same calls
+    through the Python mirror must print the same 17-digit text: the C ABI is the product, Python is one of its hosts."""
+    import os, shutil, subprocess
+    from mpopis_amd import engine as eng_mod
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mpopis_amd", "lib")
+    exe = str(tmp_path / "abi_client")
+    r = subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_client.c"), "-L" + libdir, "-lmpopis_hip",
+                        "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("step ")]
+    assert len(lines) == 5
+    eng = eng_mod.Engine("mountaincar", 0, "cemppi", 64, 15, batch=2, lam=0.1, alpha=1.0, ais_its=4, lam_ais=0.0, elite_threshold=0.8, sigma_est="mle",
+                         cma_sigma=1.0, seed=1234, cov=[1.0])
+    eng.reset()
+    for step in range(5):
+        got = eng.policy_step(None)
+        rew = eng.env_step(got["control"])
+        c = got["control"].reshape(-1)
+        want = "step %d control %.17g %.17g reward %.17g %.17g cost0 %.17g iters %d %d" % (step, c[0], c[1], rew[0], rew[1], got["cost"][0][0],
+                                                                                           got["iters_run"][0], got["iters_run"][1])
+        assert lines[step] == want, (lines[step], want)
+    eng.close()
