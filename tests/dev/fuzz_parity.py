@@ -1,10 +1,10 @@
-"""Randomised engine-vs-oracle parity sweep (dev tool; the committed tests hold fixed cases).  Random policy / cars / K / T / N / B,
-random start states, injected or device noise, random multi-stream split.  usage: python tools/fuzz_parity.py <n_cases> <seed>
+"""Randomised engine-vs-oracle parity sweep (test infrastructure: lives under tests/ because it uses the oracle; the committed tests hold fixed cases).  Random policy / cars / K / T / N / B,
+random start states, injected or device noise, random multi-stream split.  usage: python tests/dev/fuzz_parity.py <n_cases> <seed>
 A few costs per case may differ beyond 1e-7 without being a bug: rollouts that brake to a standstill chatter; the sweep
 allows ncars*K/200 of them per slot as long as control and U agree to 1e-6 (the committed tests identify those rollouts from the oracle's
 own trajectory instead)."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as O

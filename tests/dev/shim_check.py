@@ -1,6 +1,7 @@
+import os
 """CPU check of the engine's shared dynamics header (host build) against the oracle."""
 import numpy as np, ctypes as C, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
 sh=C.CDLL('tests/shim/libhost_shim.so')
 dp=C.POINTER(C.c_double)

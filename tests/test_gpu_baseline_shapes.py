@@ -175,7 +175,7 @@ def test_C5_musigma_K4096_H50_N10_device_rng(eng_mod, oracle, track):
 def test_cs300_scatter_and_global_potrf(eng_mod, oracle, track, kind):
     # K = 1024 resampled columns in 300 dimensions: Σ′ is numerically rank-deficient up to the 1e-8 ridge (cond ~ 1e7), so the
     # SECOND update inherits ~1e-8 of amplified rounding on both sides (the first agrees with a long-double recomputation to
-    # 1e-15, tools/dbg/pmc_sigma.py) -- hence the wider Σ′ tolerance here
+    # 1e-15, tests/dev/pmc_sigma.py) -- hence the wider Σ′ tolerance here
     run_case(eng_mod, oracle, track, kind, 3, 1024, 50, 3, steps=1, sig_tol=1e-6)
 
 
