@@ -126,8 +126,8 @@ __global__ void __launch_bounds__(1024) k_sortperm_lds(const double* __restrict_
 }
 
 // K <= 256 (C3: K = 150): rank sort.  Thread i counts the entries that precede entry i in the (cost, index) order -- K broadcast LDS
-// reads and compares, no barrier after the staging -- and writes order[rank] = i.  (A 36-step bitonic network on 256 slots took 9 us,
-// this takes ~2: a lone wave pays ~8 cycles per instruction whatever it does, so the instruction count is the cost.)
+// reads and compares, no barrier after the staging -- and writes order[rank] = i.  (C3: sort + early break 13.7 -> 9.2 us per iteration with
+// the 36-step bitonic network gone: a lone wave pays ~8 cycles per instruction whatever it does, so the instruction count is the cost.)
 __global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int m_elite, int* active) {
     MPOPIS_HI_PRIO();
     __shared__ __attribute__((aligned(16))) double c[256], sc[256];
