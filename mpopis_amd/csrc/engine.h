@@ -34,10 +34,10 @@ inline void ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long 
     seen.fetch_or(bit, std::memory_order_relaxed);
 }
 
-// Wave issue priority (s_setprio 0..3, default 0): every kernel of the per-slot chain EXCEPT the rollout raises it.  When the
-// two half-batch chains share the chip (engine_api.hip, policy_step_enqueue), the short latency-bound links of one chain then
-// win the SIMD issue arbitration against the other half's long-running rollout waves instead of being starved by them
-// (measured: k_weights 9 us alone, 155 us next to a rollout kernel at equal priority).
+// Wave issue priority (s_setprio 0..3, default 0): the latency-bound kernels of the per-slot chain raise it.  Whenever kernels of
+// different streams share the chip (the opt-in multi-stream schedule of policy_step_enqueue, the side chains of the CMA update, several
+// handles on one device), the short links then win the SIMD issue arbitration against long-running throughput waves instead of being
+// starved by them (measured: k_weights 9 us alone, 155 us next to a rollout kernel at equal priority).
 #define MPOPIS_HI_PRIO() __builtin_amdgcn_s_setprio(3)
 
 constexpr int kMaxCars = 4;

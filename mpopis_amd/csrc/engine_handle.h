@@ -7,14 +7,15 @@ struct mpopis_handle {
     int B = 0, K = 0, T = 0, as = 0, ss = 0, cs = 0, N = 1;
     double gamma = 0.0;
     hipStream_t stream = nullptr;
-    // Two half-batches on two streams (engine_api.hip, policy_step_enqueue): the latency-bound links of one half's chain
-    // (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) run under the other half's throughput-bound kernels
+    // Extra streams.  Opt-in multi-stream schedule (mpopis_set_overlap, policy_step_enqueue): the batch as 2..4 part-chains, the latency-bound
+    // links of one chain (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) under the others' throughput kernels.  In the default
+    // one-stream schedule the same streams carry side chains: ||L^-1||_F of the CMA update (xstream[0]) and the Z prefetch for cs > 128 (xstream[1])
     static constexpr int kMaxSplit = 4;
     hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
     bool split_pinned = false;   // MPOPIS_NSPLIT set: the schedule is fixed for the process
     bool side_free = false;      // batch not split this step: xstream[0] / ev_fork / ev_join[0] carry the CMA side chain (||L^-1||_F beside sort + elite mean)
     hipEvent_t ev_fork = nullptr, ev_join[kMaxSplit - 1] = {nullptr, nullptr, nullptr}, ev_skew[kMaxSplit - 1] = {nullptr, nullptr, nullptr};
-    int nsplit = 2;                                                            // parts the batch is split into (1 = single stream)
+    int nsplit = 1;                                                            // parts the batch is split into when split_auto is off
     bool split_auto = true;                                                    // default schedule (one stream); false: nsplit parts (mpopis_set_overlap)
     mpopis::EnvDesc env{};
     std::string err;

@@ -15,6 +15,8 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 track = O.load_track()
 kinds = ["gmppi", "imppi", "muaismppi", "musigmaaismppi", "cemppi", "pmcmppi", "cmamppi", "mppi"]
+if os.environ.get("FUZZ_KINDS"):                                   # e.g. FUZZ_KINDS=pmcmppi,cmamppi
+    kinds = os.environ["FUZZ_KINDS"].split(",")
 bad = 0
 t0 = time.time()
 for case in range(ncases):
