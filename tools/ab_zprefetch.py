@@ -1,4 +1,4 @@
-"""Same-box A/B of the Z prefetch (MPOPIS_ZPREFETCH=1/0 in subprocesses): step time of the bench workload and bit-identity of the results."""
+"""Same-box A/B of the Z prefetch (MPOPIS_ZPREFETCH=2 (forced on) / 0 in subprocesses): step time of the bench workload and bit-identity of the results."""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
@@ -16,7 +16,7 @@ print(json.dumps({"ms_per_step": ms / 20, "rollouts_per_s": rl / (ms * 1e-3), "s
 cases = [("musigmaaismppi", 1, 4096, 64), ("musigmaaismppi", 1, 4096, 8), ("cemppi", 1, 150, 1), ("pmcmppi", 1, 4096, 8), ("musigmaaismppi", 3, 4096, 8)]
 for c in cases:
     res = []
-    for z in ("1", "0", "1", "0"):
+    for z in ("2", "0", "2", "0"):
         r = subprocess.run([sys.executable, "-c", WORKER] + [str(x) for x in c], capture_output=True, text=True, env=dict(os.environ, MPOPIS_ZPREFETCH=z))
         if r.returncode != 0:
             res.append({"err": r.stderr[-300:]}); continue
