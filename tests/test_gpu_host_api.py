@@ -212,3 +212,28 @@ def test_plain_c_client_gives_the_same_numbers_as_the_python_mirror(M, tmp_path)
                                                                                            got["iters_run"][0], got["iters_run"][1])
         assert lines[step] == want, (lines[step], want)
     eng.close()
+
+
+def test_concurrent_handles_with_cooperative_kernels(M):
+    """Four handles on one device, driven from four host threads at once, all on 3-car configurations whose Cholesky / Lanczos kernels run as
+    multi-workgroup clusters with bounded spin-waits (cs = 300): every trial must finish with status 0 -- in particular never -4, the
+    code a cluster reports when a partner workgroup did not show up within its wait bound."""
+    import threading
+    res = {}
+
+    def worker(i, pt):
+        try:
+            rec, _ = M.simulate_car_racing(num_trials=4, num_steps=40, num_cars=3, policy_type=pt, num_samples=512, horizon=50, ais_its=4, seed=300 + i, quiet=True)
+            res[i] = (float(rec[:, 16].min()), int(rec[:, 2].min()))
+        except Exception as e:                                   # :cmamppi may legitimately end in the reference's PosDefException (-2)
+            res[i] = repr(e)
+    ths = [threading.Thread(target=worker, args=(i, pt)) for i, pt in enumerate([":μΣaismppi", ":cemppi", ":cmamppi", ":pmcmppi"])]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=300)
+    assert len(res) == 4
+    for i, v in res.items():
+        assert "-4" not in str(v), (i, v)
+        if isinstance(v, tuple):
+            assert v[0] in (0.0, -2.0) and v[1] >= 1, (i, v)
