@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <atomic>
 #include <string>
 #include <vector>
@@ -80,12 +81,24 @@ struct RolloutArgs {
     const int* active;     // nullptr or [B]: slots with active==0 are skipped (AIS early break)
     int* iters;            // nullptr or [B]: iters[b] = iter_n for every slot this launch works on (AIS iterations executed)
     int iter_n;
+    unsigned long long* cmin;   // nullptr or [B]: running minimum of the slot's costs as an order-preserving key (cost_key), car kernels only
+    int* status;                // with cmin: a non-finite cost sets MPOPIS_ERR_ACTION here (what k_weights reports when it runs)
 };
+// order-preserving map double -> uint64 (unsigned comparison == numeric comparison, NaN sorts last) for atomicMin on costs
+__host__ __device__ __forceinline__ unsigned long long cost_key(double v) {
+    unsigned long long u; memcpy(&u, &v, 8);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ __device__ __forceinline__ double cost_unkey(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v; memcpy(&v, &u, 8);
+    return v;
+}
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
 void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s);
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin = nullptr);
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,
@@ -131,7 +144,9 @@ bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B,
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
-                      const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr, const double* wsum = nullptr);
+                      const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr, const double* wsum = nullptr,
+                      const double* cost = nullptr, unsigned long long* cmin = nullptr, double neg_inv_lambda = 0.0);
+bool wcov_weights_from_cost_ok(int cs, int K, int ksplit);
 bool wcov_mfma_can_emit_mean(int cs);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);

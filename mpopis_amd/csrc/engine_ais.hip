@@ -63,14 +63,20 @@ int mpopis_handle::ais_update(int n, bool injected) {
         const double lam = (pol == MPOPIS_POL_IMPPI) ? cfg.lambda : cfg.lambda_ais;          // :362 / :647,:712
         // μ′, Σ′ = mean_and_cov(E, pw, 2) (:730-733).  μΣ-AIS: one pass over E yields both (ones row in the MFMA scatter)
         const bool one_pass = pol == MPOPIS_POL_MUSIGMAAISMPPI && wcov_mfma_can_emit_mean(cs);
-        time_begin(3);
-        launch_weights(d_cost, d_w, B, K, lam, d_active, d_status, stream, d_wsum);
-        if (!one_pass) launch_wmean(d_E, d_w, nullptr, nullptr, d_mu, B, cs, K, 1, d_active, stream);     // μ′ (mean(E, pw, dims=2))
-        time_end();
+        // :μΣaismppi on a car env: ws = compute_weights(IT(λ_ais), cost) (:712) is evaluated inside the moments kernel from the costs and the
+        // minimum the rollout kernel accumulated -- no reweighting launch between rollout and moments in the AIS iterations
+        const bool fold = one_pass && weights_in_moments;
+        if (!fold) {
+            time_begin(3);
+            launch_weights(d_cost, d_w, B, K, lam, d_active, d_status, stream, d_wsum);
+            if (!one_pass) launch_wmean(d_E, d_w, nullptr, nullptr, d_mu, B, cs, K, 1, d_active, stream);     // μ′ (mean(E, pw, dims=2))
+            time_end();
+        }
         if (pol == MPOPIS_POL_MUSIGMAAISMPPI) {
             time_begin(4);
             launch_wcov_mfma(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, 0.0, 10e-9, d_active, stream, nullptr,
-                             one_pass ? d_mu : nullptr, one_pass ? d_Ucur : nullptr, d_wsum);     // one pass: also pol.U += μ′
+                             one_pass ? d_mu : nullptr, one_pass ? d_Ucur : nullptr, d_wsum,
+                             fold ? d_cost : nullptr, fold ? d_cmin : nullptr, -1 / lam);        // one pass: also pol.U += μ′
             time_end();
         }
         if (!one_pass) hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);   // pol.U += μ′

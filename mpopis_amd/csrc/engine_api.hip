@@ -170,7 +170,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);
     rc |= dalloc(h, &h->d_wn, (size_t)B * cs); rc |= dalloc(h, &h->d_mu, (size_t)B * cs); rc |= dalloc(h, &h->d_gvec, (size_t)B * cs);
     rc |= dalloc(h, &h->d_dscale, (size_t)B * cs); rc |= dalloc(h, &h->d_dscale0, (size_t)cs);
-    rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B); rc |= dalloc(h, &h->d_wsum, B);
+    rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B); rc |= dalloc(h, &h->d_wsum, B); rc |= dalloc(h, &h->d_cmin, B);
     rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
     rc |= dalloc(h, &h->d_seeds, B);
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
@@ -178,6 +178,10 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
     h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));   // ~2-4 workgroups per CU in the scatter kernel
     rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
+    {
+        static const int env_fold = [] { const char* e = getenv("MPOPIS_FOLD_WEIGHTS"); return e ? atoi(e) : 1; }();      // 0: keep the separate reweighting launch (A/B)
+        h->weights_in_moments = env_fold && cfg->policy == MPOPIS_POL_MUSIGMAAISMPPI && cfg->env_kind == MPOPIS_ENV_CAR && wcov_weights_from_cost_ok(cs, K, h->ksplit);
+    }
     if (cfg->policy == MPOPIS_POL_CMAMPPI) {
         rc |= dalloc(h, &h->d_cma_scal, (size_t)B * 8); rc |= dalloc(h, &h->d_cma_vec, (size_t)B * 3 * cs); rc |= dalloc(h, &h->d_sig2, B);
         rc |= dalloc(h, &h->d_cma_ws, (size_t)K);
@@ -586,6 +590,7 @@ void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const doubl
     a.env = env; a.B = B; a.K = K; a.T = T; a.cs = cs;
     a.x0 = d_x; a.x0ext = d_xext; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
     a.cost = d_cost; a.traj = d_traj; a.active = act; a.iters = iters; a.iter_n = iter_n;
+    a.cmin = weights_in_moments ? d_cmin : nullptr; a.status = weights_in_moments ? d_status : nullptr;
     time_begin(0);
     launch_rollout(a, stream);
     time_end();
@@ -600,7 +605,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_x, ss); mv(d_xext, kMaxCars * kCarExt); mv(d_t, 1); mv(d_done, 1);
     mv(d_U, cs); mv(d_Ucur, cs); mv(d_Uin, cs);
     mv(d_Sig, nn); mv(d_L, nn); mv(d_tmpS, nn); mv(d_dscale, cs);
-    mv(d_Z, per); mv(d_E, per); mv(d_Zin, (ptrdiff_t)N * per); mv(d_cost, K); mv(d_w, K); mv(d_wsum, 1);
+    mv(d_Z, per); mv(d_E, per); mv(d_Zin, (ptrdiff_t)N * per); mv(d_cost, K); mv(d_w, K); mv(d_wsum, 1); mv(d_cmin, 1);
     mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
     mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_seeds, 1);
     mv(d_order, K); mv(d_resi, K); mv(d_alias, K); mv(d_residx_log, (ptrdiff_t)std::max(1, N - 1) * K); mv(d_resi_in, (ptrdiff_t)(N - 1) * K);
@@ -659,7 +664,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
     // status / active / iters reset, U_orig = pol.U (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop), extended start states
     launch_step_begin(status_sticky ? nullptr : d_status, d_active, alive_gate, d_iters, d_U, d_Uin, d_Ucur, B, cs,
-                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream);
+                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream, weights_in_moments ? d_cmin : nullptr);
     if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
     if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
     // Shapes the fused sampler does not cover (cs > 128: Z goes through memory anyway) with device RNG, a dense proposal from iteration 2 on

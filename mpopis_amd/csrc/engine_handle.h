@@ -29,6 +29,8 @@ struct mpopis_handle {
     bool sigma_diag = false;
     // samples / costs / weights
     double *d_Z = nullptr, *d_E = nullptr, *d_Zin = nullptr, *d_cost = nullptr, *d_w = nullptr;
+    unsigned long long* d_cmin = nullptr;   // [B] running minimum cost of the last rollout launch (cost_key), when the AIS reweighting is folded into the moments kernel
+    bool weights_in_moments = false;        // :μΣaismppi on a car env with a shape that allows it (engine_api.hip, create)
     double* d_wsum = nullptr;          // [B] Σ_k w_k of the last k_weights launch of the AIS loop
     double *d_wn = nullptr, *d_mu = nullptr, *d_gvec = nullptr, *d_control = nullptr, *d_reward = nullptr, *d_traj = nullptr;
     int *d_status = nullptr, *d_active = nullptr, *d_iters = nullptr;

@@ -153,7 +153,8 @@ template <int KC, bool SQ>
 __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
                                                            const double* __restrict__ mu, const double* __restrict__ rscale,
                                                            double* __restrict__ part, int cs, int K, int m,
-                                                           int ksplit, int npairs, const int* active, int aug) {
+                                                           int ksplit, int npairs, const int* active, int aug,
+                                                           const double* __restrict__ costp, const unsigned long long* __restrict__ cminp, double neg_inv_lambda) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     constexpr int kRowStep = 256 / KC;
     double* Xs = smem;                                          // [rows_pad][S]
     double* ws = smem + (size_t)rows_pad * S;                   // [KC]
+    double* wsl = ws + KC;                                      // [per] (weights-from-costs form) the k range's unnormalised weights
     const double* Xb = X + (size_t)b * cs * K;
     const double* wb = w ? w + (size_t)b * K : nullptr;
     const int32_t* ib = idx ? idx + (size_t)b * K : nullptr;
@@ -193,11 +195,20 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
             rsreg[u] = rscale[(size_t)b * cs + min(sr0 + u * kRowStep, cs - 1)];
         }
     }
+    if (costp) {
+        // Weights from costs: w_k = exp(-1/λ (c_k - ρ)) (compute_weights, utils.jl:79-86) with ρ = the minimum the rollout kernel accumulated.
+        // Left UNnormalised: the moments divide by Σ_k w_k, which comes out of the same pass (ones row x ones row of the augmented scatter),
+        // so the separate reweighting launch between rollout and moments disappears.  Done before the main loop, while the staging registers
+        // are still free.
+        const double rho = cost_unkey(cminp[b]);
+        for (int kq = kbeg + (int)threadIdx.x; kq < kend; kq += 256) wsl[kq - kbeg] = exp(neg_inv_lambda * (costp[(size_t)b * K + kq] - rho));
+        __syncthreads();
+    }
     bool kin_cur = false;
     auto load_chunk = [&](int c0) {                             // unconditional loads from clamped addresses
         const int kq = min(c0 + skk, kend - 1);
         const int col = ib ? ib[kq] : kq;
-        wreg = wb ? wb[col] : 1.0;
+        wreg = costp ? wsl[kq - kbeg] : (wb ? wb[col] : 1.0);
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) xreg[u] = Xb[(size_t)min(sr0 + u * kRowStep, cs - 1) * K + col];
     };
@@ -245,14 +256,26 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
 __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restrict__ part, const double* __restrict__ w, double* __restrict__ Sg,
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
                                                           const double* __restrict__ mu_corr, double wtot_unweighted,
-                                                          double* __restrict__ mu_aug, double* __restrict__ u_add, const double* __restrict__ wsum) {
+                                                          double* __restrict__ mu_aug, double* __restrict__ u_add, const double* __restrict__ wsum,
+                                                          unsigned long long* cmin_reset) {
     MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     __shared__ double sh[4];
     __shared__ double sden, swtot;
     __shared__ double smu[32];
-    if (w && wsum) { if (threadIdx.x == 0) { swtot = wsum[b]; sden = (den == 0.0) ? swtot : den; } __syncthreads(); }   // precomputed by k_weights
+    if (cmin_reset) {
+        // weights-from-costs form: Σ_k w_k is the (ones row, ones row) entry of the augmented scatter
+        if (threadIdx.x == 0) {
+            const int taug = cs >> 4, il = cs & 15;
+            const int qa = taug * (taug + 1) / 2 + taug, ea = (((il & 3) * 16 + il) << 2) + (il >> 2);
+            double t = 0.0;
+            for (int sp = 0; sp < ksplit; ++sp) t += part[(((size_t)b * ksplit + sp) * npairs + qa) * 256 + ea];
+            swtot = t; sden = (den == 0.0) ? t : den;
+            if (blockIdx.x == 0) cmin_reset[b] = ~0ull;                        // the next rollout launch starts a fresh minimum
+        }
+        __syncthreads();
+    } else if (w && wsum) { if (threadIdx.x == 0) { swtot = wsum[b]; sden = (den == 0.0) ? swtot : den; } __syncthreads(); }   // precomputed by k_weights
     else if (w) {                                               // Σ_k w_k (ProbabilityWeights)
         double sacc = 0.0;
         for (int k = threadIdx.x; k < K; k += 256) sacc += w[(size_t)b * K + k];
@@ -394,11 +417,14 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
 bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
-                      double* mu_out, double* u_add, const double* wsum) {
+                      double* mu_out, double* u_add, const double* wsum, const double* cost, unsigned long long* cmin, double neg_inv_lambda) {
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
+    const bool from_cost = cost && cmin && aug && !idx && wcov_weights_from_cost_ok(cs, K, ksplit);
+    if (!from_cost) { cost = nullptr; cmin = nullptr; }
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
-    const size_t lds = ((size_t)nt * 16 * (kc + 1) + kc) * sizeof(double);
+    const int per = ((m + ksplit - 1) / ksplit + kc - 1) / kc * kc;
+    const size_t lds = ((size_t)nt * 16 * (kc + 1) + kc + (from_cost ? per : 0)) * sizeof(double);
     static std::atomic<unsigned long long> seen[4];
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, false>, 96 * 1024, seen[0]);
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<16, false>, 96 * 1024, seen[1]);
@@ -406,14 +432,20 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<16, true>, 96 * 1024, seen[3]);
     const dim3 grid(ksplit, (npairs + kPairsPerBlock - 1) / kPairsPerBlock, B);
     if (rscale) {
-        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
-        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
     } else {
-        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
-        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug);
+        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
+        else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
-                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr, wsum);
+                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr, wsum, cmin);
+}
+// the weights-from-costs form needs the ones row (cs not a multiple of 16) and keeps a split's weights in LDS
+bool wcov_weights_from_cost_ok(int cs, int K, int ksplit) {
+    const int kc = wcov_kc(cs);
+    const int per = ((K + ksplit - 1) / ksplit + kc - 1) / kc * kc;
+    return wcov_mfma_can_emit_mean(cs) && per <= 1024;
 }
 
 }  // namespace mpopis

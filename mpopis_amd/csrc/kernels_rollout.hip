@@ -102,17 +102,26 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
         }
     }
     cost += cc;
+    double total = cost;
+    bool writer = true;
     if (NC > 1) {
         sh_cost[g][c][lane] = cost;
         __syncthreads();
+        writer = (c == 0);
         if (c == 0) {
-            double tot = cost;
 #pragma unroll
-            for (int j = 1; j < NC; ++j) tot += sh_cost[g][j][lane];
-            if (valid) a.cost[(size_t)b * K + k] = tot;
+            for (int j = 1; j < NC; ++j) total += sh_cost[g][j][lane];
         }
-    } else {
-        if (valid) a.cost[(size_t)b * K + k] = cost;
+    }
+    if (writer && valid) a.cost[(size_t)b * K + k] = total;
+    if (a.cmin && writer) {
+        // ρ = minimum(costs) (utils.jl:81) accumulates here, one atomic per wave, so that the AIS reweighting can be folded into the moments
+        // kernel (launch_wcov_mfma, weights from costs) instead of a launch of its own between the two
+        unsigned long long key = valid ? cost_key(total) : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
+        if (lane == 0) atomicMin(&a.cmin[b], key);
+        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
     }
 }
 
@@ -170,9 +179,9 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
 // status = 0 (unless sticky), active = alive gate (or 1), iters = 0, U_orig = the loop's pol.U = pol.U, and the car start states extended
 // with sin/cos of psi / delta (as k_extend_state).
 __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur,
-                                                    int cs, const double* x, double* xext, int ncars) {
+                                                    int cs, const double* x, double* xext, int ncars, unsigned long long* cmin) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; }
+    if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; if (cmin) cmin[b] = ~0ull; }
     for (int i = tid; i < cs; i += 256) { const double u = U[(size_t)b * cs + i]; Uin[(size_t)b * cs + i] = u; Ucur[(size_t)b * cs + i] = u; }
     if (x && tid < ncars) {
         const size_t i = (size_t)b * ncars + tid;
@@ -184,8 +193,8 @@ __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, co
     }
 }
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st) {
-    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin) {
+    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin);
 }
 
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
