@@ -264,9 +264,27 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     __shared__ double sh[4];
     __shared__ double sden, swtot;
     __shared__ double smu[32];
+    const int q = blockIdx.x;
+    int ta, tb;
+    decode_pair(q, &ta, &tb);
+    const int e = threadIdx.x;                                  // e = lane*4 + r  (lane 0..63, r 0..3)
+    const int lane = e >> 2, r = e & 3;
+    const int ia = ta * 16 + (lane >> 4) + 4 * r, ibb = tb * 16 + (lane & 15);
+    // Every sum over the K-split partials this block needs -- its own entry, the 32 mean entries, the sum of weights -- is loaded BEFORE the first
+    // barrier: the kernel is three dependent global round trips otherwise (a few workgroups' worth of data, ~2 us each).
+    double v = 0.0;
+    for (int sp = 0; sp < ksplit; ++sp) v += part[(((size_t)b * ksplit + sp) * npairs + q) * 256 + e];
+    double msum = 0.0;
+    if (mu_aug && threadIdx.x < 32) {
+        // μ_j = (row cs of the augmented scatter)_j / Σw: element (cs % 16, j % 16) of tile pair (cs / 16, j / 16)
+        const int t = (threadIdx.x < 16) ? ta : tb, jl = threadIdx.x & 15;
+        const int taug = cs >> 4, il = cs & 15;
+        const int qa = taug * (taug + 1) / 2 + t, ea = (((il & 3) * 16 + jl) << 2) + (il >> 2);
+        for (int sp = 0; sp < ksplit; ++sp) msum += part[(((size_t)b * ksplit + sp) * npairs + qa) * 256 + ea];
+    }
     if (cmin_reset) {
         // weights-from-costs form: Σ_k w_k is the (ones row, ones row) entry of the augmented scatter
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 32) {
             const int taug = cs >> 4, il = cs & 15;
             const int qa = taug * (taug + 1) / 2 + taug, ea = (((il & 3) * 16 + il) << 2) + (il >> 2);
             double t = 0.0;
@@ -287,21 +305,10 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
         __syncthreads();
     } else { if (threadIdx.x == 0) { sden = den; swtot = wtot_unweighted; } __syncthreads(); }
     const double inv = 1 / sden;
-    const int q = blockIdx.x;
-    int ta, tb;
-    decode_pair(q, &ta, &tb);
-    const int e = threadIdx.x;                                  // e = lane*4 + r  (lane 0..63, r 0..3)
-    const int lane = e >> 2, r = e & 3;
-    const int ia = ta * 16 + (lane >> 4) + 4 * r, ibb = tb * 16 + (lane & 15);
     if (mu_aug) {
-        // μ_j = (row cs of the augmented scatter)_j / Σw: element (cs % 16, j % 16) of tile pair (cs / 16, j / 16)
         if (threadIdx.x < 32) {
-            const int t = (threadIdx.x < 16) ? ta : tb, jl = threadIdx.x & 15;
-            const int taug = cs >> 4, il = cs & 15;
-            const int qa = taug * (taug + 1) / 2 + t, ea = (((il & 3) * 16 + jl) << 2) + (il >> 2);
-            double m = 0.0;
-            for (int sp = 0; sp < ksplit; ++sp) m += part[(((size_t)b * ksplit + sp) * npairs + qa) * 256 + ea];
-            m = m / swtot;
+            const int jl = threadIdx.x & 15, taug = cs >> 4;
+            const double m = msum / swtot;
             smu[threadIdx.x] = m;
             if (ta == taug && threadIdx.x >= 16 && tb * 16 + jl < cs) {
                 mu_aug[(size_t)b * cs + tb * 16 + jl] = m;
@@ -312,8 +319,6 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
     }
     if (ia >= cs || ibb >= cs) return;
     if (ta == tb && ibb > ia) return;
-    double v = 0.0;
-    for (int sp = 0; sp < ksplit; ++sp) v += part[(((size_t)b * ksplit + sp) * npairs + q) * 256 + e];
     if (mu_aug) v = fma(-smu[ia - ta * 16] * swtot, smu[16 + ibb - tb * 16], v);
     else if (mu_corr) v = fma(-mu_corr[(size_t)b * cs + ia] * swtot, mu_corr[(size_t)b * cs + ibb], v);
     v = v * inv;
