@@ -528,7 +528,17 @@ __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ 
     const double* x = X + ((size_t)b * cs + r) * K;
     const int32_t* ib = idx + (size_t)b * K;          // idx arrays are K long per slot (order / resample)
     double acc = 0.0;
-    for (int j = threadIdx.x; j < m; j += 256) acc = cw ? fma(cw[j], x[ib[j]], acc) : acc + x[ib[j]];
+    // index -> value is two dependent global round trips per element: issue them 8 elements at a time (m = K = 4096 for :pmcmppi is 16
+    // elements per thread -- 32 serial round trips as a plain loop); same summation order as the plain loop
+    for (int j0 = threadIdx.x; j0 < m; j0 += 256 * 8) {
+        int ii[8]; double xv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = min(j0 + 256 * u, m - 1); ii[u] = ib[j]; wv[u] = cw ? cw[j] : 1.0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = x[ii[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (j0 + 256 * u < m) acc = cw ? fma(wv[u], xv[u], acc) : acc + xv[u];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
