@@ -43,6 +43,29 @@ __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cos
     double* wo = w + (size_t)b * K;
     double m = INFINITY;
     bool bad = false;
+    if (K <= 8 * (int)blockDim.x) {
+        // the slot's costs fit the workgroup's registers (<= 8 per thread): one read of the costs, one write of the weights, instead of three
+        // passes through memory with a dependent round trip each; same per-thread summation order as the loops below (bit-identical)
+        double cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = threadIdx.x + u * blockDim.x; cv[u] = (k < K) ? c[k] : INFINITY; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = threadIdx.x + u * blockDim.x; if (k < K) { m = fmin(m, cv[u]); bad |= !(fabs(cv[u]) < INFINITY); } }
+        m = block_reduce<true>(m, sh);                                         // ρ = minimum(costs)
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = threadIdx.x + u * blockDim.x; if (k < K) { cv[u] = exp(neg_inv_lambda * (cv[u] - m)); s += cv[u]; } }
+        s = block_reduce<false>(s, sh);                                        // η
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = threadIdx.x + u * blockDim.x; if (k < K) { const double v = cv[u] / s; wo[k] = v; t += v; } }
+        if (wsum) {
+            t = block_reduce<false>(t, sh);
+            if (threadIdx.x == 0) wsum[b] = t;
+        }
+        if (bad && status) atomicMin(&status[b], MPOPIS_ERR_ACTION);
+        return;
+    }
     for (int k = threadIdx.x; k < K; k += blockDim.x) { const double v = c[k]; m = fmin(m, v); bad |= !(fabs(v) < INFINITY); }
     m = block_reduce<true>(m, sh);                                             // ρ = minimum(costs)
     double s = 0.0;
