@@ -152,6 +152,7 @@ void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);
 void launch_fill_f64(double* p, double v, size_t n, hipStream_t s);
 void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s);
+void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s);
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);
 

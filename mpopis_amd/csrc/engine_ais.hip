@@ -97,6 +97,15 @@ int mpopis_handle::ais_update(int n, bool injected) {
         launch_alias_sample(d_accept, d_alias, di, stride, du, d_order, d_residx_log + (size_t)(n - 1) * K, (size_t)(N - 1) * K, B, K, d_active, stream);
         time_end();
         time_begin(4);
+        if (wcov_mfma_can_emit_mean(cs)) {
+            // E′ = E[:, idx] materialised once (d_Z is free between two sampling phases; the Z prefetch is off for this policy), then
+            // (μ′, Σ′) = mean_and_cov(E′, 2) (corrected, :807) in ONE pass over the contiguous E′: ones row for the mean, no per-element gather
+            launch_gather_cols(d_E, d_order, d_Z, B, cs, K, d_active, stream);
+            launch_wcov_mfma(d_Z, nullptr, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream, nullptr,
+                             d_mu, d_Ucur);                                                    // also pol.U += μ′ (:809)
+            time_end();
+            return MPOPIS_OK;
+        }
         launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, K, 1, d_active, stream);   // mean_and_cov(E[:,idx], 2): corrected
         launch_wcov_mfma(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream);
         time_end();

@@ -672,7 +672,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     // (C5, 64 trials: 6.72 vs 6.45 ms per step: the drawing then competes with the moments kernel instead of filling the MFMA bubbles of
     // the fused kernel); MPOPIS_ZPREFETCH=2 forces it for such A/B runs, 0 disables it.
     static const int env_zpre = [] { const char* e = getenv("MPOPIS_ZPREFETCH"); return e ? atoi(e) : 1; }();
-    const bool z_prefetch_ok = env_zpre && (env_zpre == 2 || !sample_trmm_fusable(cs)) && side_free && xstream[1] && !injected && pol != MPOPIS_POL_MPPI &&
+    const bool z_prefetch_ok = env_zpre && (env_zpre == 2 || !sample_trmm_fusable(cs)) && side_free && xstream[1] && !injected && pol != MPOPIS_POL_MPPI && pol != MPOPIS_POL_PMCMPPI /* d_Z holds E[:, idx] there */ &&
                                !(sigma_diag && sigma_fixed) && N > 1;
     bool z_prefetched = false;
     for (int n = 1; n <= N; ++n) {

@@ -545,6 +545,17 @@ __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) { double t = sh[0] + sh[1] + sh[2] + sh[3]; mu[(size_t)b * mu_stride + r] = divide ? t / m : t; }
 }
+// Xout[b][r][k] = X[b][r][idx[b][k]]: E′ = E[:, idx] (:806) as a contiguous matrix (coalesced index reads and writes; the random reads stay inside
+// one 8K-byte row), so that the moments of the resampled columns run through the un-gathered fast path of the scatter kernel
+__global__ void __launch_bounds__(256) k_gather_cols(const double* __restrict__ X, const int32_t* __restrict__ idx, double* __restrict__ Xout, int cs, int K,
+                                                     const int* active) {
+    const int b = blockIdx.z, r = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if ((active && !active[b]) || k >= K) return;
+    Xout[((size_t)b * cs + r) * K + k] = X[((size_t)b * cs + r) * K + idx[(size_t)b * K + k]];
+}
+void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_cols, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, X, idx, Xout, cs, K, active);
+}
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_mean, dim3(cs, B), dim3(256), 0, s, X, idx, cw, mu, (size_t)cs, cs, K, m, divide, active);
