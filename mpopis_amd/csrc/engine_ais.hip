@@ -117,7 +117,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         if (side) {
             // tr(Σ^-1) = σ² ||L^-1||_F² needs only L = chol(σ²Σ): a latency-bound kernel of a few workgroups, run beside the equally
             // latency-bound sort / elite mean on the free second stream (beside the rollout it cost the rollout more than it saved)
-            (void)hipEventRecord(ev_fork, stream);
+            if (!fork_recorded) (void)hipEventRecord(ev_fork, stream);          // the Z prefetch may already have marked the point behind the rollout
             (void)hipStreamWaitEvent(xstream[0], ev_fork, 0);
             launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, xstream[0]);
             (void)hipEventRecord(ev_join[0], xstream[0]);

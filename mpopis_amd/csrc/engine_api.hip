@@ -718,10 +718,12 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         if (n == 1 && record_after_first_sampler) (void)hipEventRecord(record_after_first_sampler, stream);   // the next part starts when this one enters its first rollout
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active, d_iters, n);   // also records iters_run = n for the active slots
+        fork_recorded = false;
         if (z_prefetch_ok && n < N) {
             // Z of iteration n+1 depends on nothing but (seed, MPC step, iteration): draw it now, beside the latency-bound kernels that follow
-            (void)hipEventRecord(ev_skew[0], stream);
-            (void)hipStreamWaitEvent(xstream[1], ev_skew[0], 0);
+            (void)hipEventRecord(ev_fork, stream);                      // one fork point behind the rollout for both side chains (an event
+            fork_recorded = true;                                       // record on the main stream costs ~6 us of its critical path)
+            (void)hipStreamWaitEvent(xstream[1], ev_fork, 0);
             launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, d_active, xstream[1]);
             (void)hipEventRecord(ev_skew[1], xstream[1]);
             z_prefetched = true;
