@@ -89,6 +89,84 @@ def cpu_baseline(seconds_target=12.0):
             "mpc_steps_per_s": steps / t_total}
 
 
+def alg_bytes(policy, cs):
+    """SURVEY 8(d) / BASELINE.md section 3: 8*(3*cs+4) B per rollout, one more cs-row pass for the policies that adapt Σ′."""
+    return 8 * ((4 if policy in ("μΣaismppi", "cemppi", "cmamppi", "pmcmppi") else 3) * cs + 4)
+
+
+def measure_config(name, policy, cars, Kc, Nc, trials, steps, device, closed_loop=False, **kw):
+    """One BASELINE config on this GPU, device RNG, `trials` resident trials: ms per MPC step (HIP events / wall around `steps` steps after a
+    warm-up), rollouts/s, MPC steps/s, per-class kernel time of a step, the dominant class and its average launch.  closed_loop: the resident
+    closed loop (mpopis_run_trials: policy step + env step per MPC step) -- used for :cmamppi, whose Σ update needs the state to move
+    (DESIGN.md section 5); otherwise mpopis_bench_policy_steps like the headline workload."""
+    import numpy as np
+    from mpopis_amd.engine import Engine
+    cs = 2 * cars * H
+    eng = Engine("car", cars, policy, Kc, H, batch=trials, lam=LAM, alpha=1.0, ais_its=Nc, lam_ais=LAM_AIS, cov=np.tile([0.0625, 0.1], cars),
+                 seed=20240000, device=device, **kw)
+    try:
+        if closed_loop:
+            eng.run_trials(num_steps=1, laps=2)                                   # warm-up: 2 MPC steps
+            eng.reset(); eng.set_U(np.zeros((trials, cs))); eng.seed(20240000)
+            t0 = time.perf_counter()
+            rec = eng.run_trials(num_steps=steps - 1, laps=2)
+            ms = (time.perf_counter() - t0) * 1e3
+            rollouts = float(rec[:, 14].sum())
+            eng.reset(); eng.set_U(np.zeros((trials, cs))); eng.seed(20240000)
+            tsteps = min(steps, 4)
+            eng.timing_enable(True); eng.timing_reset()
+            eng.run_trials(num_steps=tsteps - 1, laps=2)
+        else:
+            eng.bench_policy_steps(max(3, steps // 4))
+            ms, rollouts = eng.bench_policy_steps(steps)
+            tsteps = min(steps, 5)
+            eng.timing_enable(True); eng.timing_reset()
+            eng.bench_policy_steps(tsteps)
+        tm = eng.timing_read()
+        eng.timing_enable(False)
+    finally:
+        eng.close()
+    per_step = {k: v[0] / tsteps for k, v in tm.items() if v[1]}
+    dom = max(per_step, key=per_step.get)
+    rps = rollouts / (ms * 1e-3)
+    ba = alg_bytes(policy, cs)
+    return {"config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
+            "loop": "closed loop (mpopis_run_trials)" if closed_loop else "policy steps (mpopis_bench_policy_steps)",
+            "kernel_ms_per_step": per_step, "dominant": {"class": dom, "avg_launch_us": tm[dom][0] / tm[dom][1] * 1e3, "share_of_kernel_time": per_step[dom] / sum(per_step.values())},
+            "alg_bytes_per_rollout": ba, "hbm_frac": rps * ba / (HBM_PEAK_GBS * 1e9), "fp64_reference_algorithm_frac": rps * 3.5e5 * cars / (FP64_PEAK_TFLOPS * 1e12)}
+
+
+def baseline_configs(device, quick=False):
+    """BASELINE.json configs[1..3] (C2, C3, C4) at one resident trial (the reference's own usage) and at chip-filling batches."""
+    out = []
+    S = 3 if quick else 1
+    for trials in ((1, 64) if not quick else (1,)):
+        out.append(measure_config("C2 Car-Racing 1-car :gmppi K=1024 H=50", "gmppi", 1, 1024, 1, trials, 40 // S, device))
+    for trials in ((1, 64) if not quick else (1,)):
+        out.append(measure_config("C3 Car-Racing 1-car :cemppi K=150 H=50 N=10 elite=0.8 Σ_est=:ss", "cemppi", 1, 150, 10, trials, 20 // S, device, sigma_est="ss", elite_threshold=0.8))
+    for trials in ((1, 8, 32, 64) if not quick else (1,)):
+        out.append(measure_config("C4 Car-Racing 3-car :cmamppi K=4096 H=50 N=10", "cmamppi", 3, 4096, 10, trials, 10 // S, device, closed_loop=True, elite_threshold=0.8, cma_sigma=0.75))
+    return out
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU, rank r -> cuda:r, rendezvous
+    on 127.0.0.1) by re-executing this file under torch.distributed.run with the same arguments; rank 0's JSON line is the only thing
+    on stdout.  The trial loop this shards is src/examples/car_example.jl:170-188."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +174,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=10, help="extra repetitions of the timed region (after it), for median / min / max")
+    ap.add_argument("--no-configs", action="store_true", help="skip the C2/C3/C4 block (BASELINE configs[1..3])")
+    ap.add_argument("--quick-configs", action="store_true", help="C2/C3/C4 at one trial and fewer steps only (tests)")
     ap.add_argument("--multi-stream", action="store_true", help="also time the opt-in four-part schedule (mpopis_set_overlap(h, 4)) after the timed region")
     # development aids for exercising the N > 1 control flow on a 1-GPU box (never used by the driver): all ranks on cuda:0 over gloo.
     # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
@@ -103,12 +184,15 @@ def main():
     ap.add_argument("--same-gpu", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus)
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE (%d) != --gpus (%d): launch N ranks or none (bench.py spawns them itself)" % (world, args.gpus))
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -211,6 +295,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     tm = eng.timing_read()
+    # R more repetitions of the same timed region (same bracketing), for the spread: median / min / max over R+1 samples.
+    samples = [dt]
+    for _ in range(max(0, args.repeats)):
+        sync()
+        t0r = time.perf_counter()
+        eng.bench_policy_steps(args.steps)
+        if dist is not None:
+            summary_gather(eng)
+        sync()
+        tr = torch.tensor([time.perf_counter() - t0r], device=cdev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        samples.append(float(tr.item()))
     # Outside the timed region: per-class kernel times of a step (same schedule) and, with --multi-stream, the same workload in the opt-in
     # multi-stream schedule (mpopis_set_overlap(h, 4): four skewed part-chains on their own streams), reported next to the timed figure.
     eng.timing_enable(True); eng.timing_reset()
@@ -260,14 +357,18 @@ def main():
         ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
         ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
         m_ms, m_n = tm_multi["rollout"]
-        traffic, valu_busy = None, None
+        traffic, valu_busy, flops_exec = None, None, None
         pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")      # written by tools/pmc_summary.py from separate --pmc passes
         if os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
                 traffic, valu_busy = pm.get("hbm_bytes_per_rollout") * per_launch, pm.get("valu_busy_frac")
+                flops_exec = pm.get("fp64_flops_per_rollout")
             except Exception:
                 traffic = None
+        srt = sorted(samples)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        step_bytes = total_rollouts / world * BYTES_PER_ROLLOUT            # per GPU: algorithmic bytes of the whole path in the timed region
         out = {
             "metric": "trajectory rollouts/sec (+ MPC steps/sec), Car-Racing K=4096 H=50",
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,14 +377,22 @@ def main():
             "mpc_steps_per_s": B * world * args.steps / dt,
             "config": {"workload": "Car-Racing 1-car :μΣaismppi K=4096 H=50 N=10 λ=10 λ_ais=20, %d independent trials per GPU (BASELINE configs[4])" % B,
                        "trials_per_gpu": B, "rollouts_per_step": int(B * N_AIS * K), "prewarm_steps": PREWARM_STEPS, "parallelism": "trials sharded x%d, RCCL gather of summary stats" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_rollout_car<1, 4, false>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "repeats": {"n": len(samples), "what": "the timed region repeated back to back (first sample = the contract's timed region = `value`)",
+                        "ms_per_step": {"median": med / args.steps * 1e3, "min": srt[0] / args.steps * 1e3, "max": srt[-1] / args.steps * 1e3},
+                        "value": {"median": total_rollouts / med, "max": total_rollouts / srt[0], "min": total_rollouts / srt[-1]}},
+            "roofline": {"bound": "fp64_valu", "contract_bound": "hbm", "kernel": "k_rollout_car<1, 4, false>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_definition": "contract formula: whole-path algorithmic bytes per launch (SURVEY 8d: %d B x rollouts per launch) / the dominant kernel's average launch time / 8 TB/s" % BYTES_PER_ROLLOUT,
+                         "what_binds": "FP64 VALU issue of the rollout kernel (HBM is at kernel_traffic_frac of peak: nothing is re-read; no MFMA in this kernel)",
+                         "step_frac": step_bytes / dt / (HBM_PEAK_GBS * 1e9),
+                         "kernel_traffic_frac": (traffic / r_avg_s / (HBM_PEAK_GBS * 1e9)) if traffic else None,
+                         "fp64_executed_frac": (flops_exec * per_launch / r_avg_s / (FP64_PEAK_TFLOPS * 1e12)) if flops_exec else None,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "rollouts_per_launch": per_launch, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
                          "schedule": "timed region = the engine's default schedule (one stream): %d launch per AIS iteration, all %d trials in one launch, nothing else on the GPU while it runs" % (max(1, round(r_n / (args.steps * N_AIS))), B),
                          "multi_stream": ({"what": "same workload, opt-in schedule mpopis_set_overlap(h, 4) (four part-chains on their own streams), measured right after the timed region; a launch then covers a quarter of the trials and shares the chip with the other chains' kernels, so its duration is not a kernel-in-isolation figure",
                                            "ms_per_step": ms_multi / args.steps, "value": rl_multi / (ms_multi * 1e-3), "rollout_avg_launch_us": (m_ms / max(m_n, 1)) * 1e3, "rollout_launches": m_n}
                                           if ms_multi is not None else "not measured (python bench.py --multi-stream; DESIGN.md section 5 has the same-box A/B: 1-3 % faster steps at >= 64 trials)"),
-                         "binding_resource": "FP64 VALU issue (not HBM, not MFMA); valu_busy_frac from the PMC pass in profiles/",
+                         "bound_note": "achieved / peak / frac are the HBM figure the bench contract prescribes (contract_bound); `bound` names the resource that actually limits the kernel; valu_busy_frac from the PMC pass in profiles/",
                          "valu_busy_frac": valu_busy,
                          "fp64_reference_algorithm_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
                          "fp64_reference_algorithm_frac": ach_tf / FP64_PEAK_TFLOPS,
@@ -293,6 +402,8 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
+        if not args.no_configs and world == 1:
+            out["configs"] = baseline_configs(local_rank, quick=args.quick_configs)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out, ensure_ascii=False))

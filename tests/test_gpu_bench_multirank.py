@@ -38,3 +38,36 @@ def test_bench_two_ranks_on_one_gpu():
     assert r["rollouts_per_launch"] * r["launches"] == 64 * 10 * 4096 * 2          # per-launch accounting matches the schedule
     assert 0 < r["frac"] < 1 and r["launches"] == 2 * 10                      # default schedule: one launch per AIS iteration, all trials
     assert r["multi_stream"]["ms_per_step"] > 0 and r["multi_stream"]["rollout_launches"] == 4 * 2 * 10      # --multi-stream pass
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver starts it): bench.py spawns its two ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "2",
+           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["strong_scaling"]["trials_per_gpu"] == 32
+    assert d["repeats"]["n"] == 3 and d["repeats"]["ms_per_step"]["min"] <= d["repeats"]["ms_per_step"]["median"] <= d["repeats"]["ms_per_step"]["max"]
+    assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
+
+
+def test_bench_single_gpu_line_has_every_baseline_config():
+    """N = 1 line: contract fields, repeats statistics, roofline extras and the C2/C3/C4 block (quick variant: one trial each)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--quick-configs"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["unit"] == "rollouts/s" and d["dtype"] == "f64"
+    r = d["roofline"]
+    assert 0 < r["step_frac"] < r["frac"] < 1 and 0 < r["kernel_traffic_frac"] < 1 and 0 < r["fp64_executed_frac"] < 1
+    names = [c["config"][:2] for c in d["configs"]]
+    assert names == ["C2", "C3", "C4"]
+    for c in d["configs"]:
+        assert c["ms_per_step"] > 0 and c["rollouts_per_s"] > 0 and c["dominant"]["avg_launch_us"] > 0
+        assert abs(sum(c["kernel_ms_per_step"].values()) - c["ms_per_step"]) < 0.5 * c["ms_per_step"]      # kernel classes account for the step

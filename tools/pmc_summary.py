@@ -52,6 +52,7 @@ if ro:
            "hbm_bytes_per_rollout": (2 * fetch_kib * 1024 + write_kib * 1024) / (B * K),
            "valu_insts_per_rollout": (r.get("SQ_INSTS_VALU") or 0.0) / (B * K / 64.0),
            "fp64_valu_insts_per_rollout": sum((r.get(c) or 0.0) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")) / (B * K / 64.0),
+           "fp64_flops_per_rollout": 64.0 * (2 * (r.get("SQ_INSTS_VALU_FMA_F64") or 0.0) + sum((r.get(c) or 0.0) for c in ("SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64"))) / (B * K),
            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
            "valu_busy_frac": ((r.get("SQ_ACTIVE_INST_VALU") or 0.0) * 4.0) / (((r.get("GRBM_GUI_ACTIVE") or 1.0) / 8.0) * 1024.0),
            "effective_clock_ghz": ((r.get("GRBM_GUI_ACTIVE") or 0.0) / 8.0) / (r["avg_us"] * 1e3),
