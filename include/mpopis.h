@@ -34,7 +34,12 @@
 extern "C" {
 #endif
 
-#define MPOPIS_ABI_VERSION 1
+/* ABI history.  1: round-1 surface.  2: + mpopis_seed_slots, mpopis_get_Sigma, mpopis_set_overlap, mpopis_comm_unique_id / _init / _destroy,
+ * mpopis_gather_summary, and the error code MPOPIS_ERR_NUMERIC.  A version-1 caller keeps working against a version-2 library (nothing was
+ * removed or changed in meaning); a caller that needs the newer entry points checks mpopis_abi_version() >= 2.
+ * Error precedence when several slots / kernels fail in one call: MPOPIS_ERR_HIP > MPOPIS_ERR_ACTION > MPOPIS_ERR_NOT_PD > MPOPIS_ERR_NUMERIC --
+ * the version-1 codes keep their order (numeric minimum) and are never hidden by MPOPIS_ERR_NUMERIC. */
+#define MPOPIS_ABI_VERSION 2
 
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };
 

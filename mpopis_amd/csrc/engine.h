@@ -130,10 +130,30 @@ void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const u
                                   const int* active, hipStream_t s);
 
 
+// Workspace of the cooperative ("cluster") kernels: several workgroups per matrix that exchange through global memory and therefore need
+// to be co-resident.  Co-residency is planned (grid <= coop_max_workgroups() of the device) but never assumed: every wait is bounded, a
+// cluster that gives up marks its slot in `redo`, counts the event in `timeouts`, and the launch is followed by the one-workgroup kernel
+// predicated on `redo` -- a slot is only ever reported failed by the kernel that needs no partner.  The host disables the cooperative
+// kernels of a handle after the first recorded time-out (sync_status), so a device that cannot hold the clusters (partitioned GPU, many
+// handles / processes) pays the bounded wait once.
+struct CoopCtx {
+    unsigned long long* flags = nullptr;   // potrf: [B][ceil(n/16)] panel flags; Lanczos: exchange granules (invsqrt_coop_words)
+    unsigned long long* epoch = nullptr;   // host-side launch counter (tags)
+    int* redo = nullptr;                   // [B] slot must be recomputed by the one-workgroup kernel (set on a time-out, cleared by the fall-back)
+    int* timeouts = nullptr;               // [1] time-outs since the handle was created
+    int share = 1;                         // cluster launches of this handle that may be in flight at once (multi-stream schedule): each gets 1/share of the device
+    bool usable() const { return flags && epoch && redo && timeouts; }
+};
+int coop_max_workgroups();                 // per current device: its CU count (one 150 KB-LDS workgroup per CU)
+// bounded wait of a cluster member for its partners in ticks of the 100 MHz wall clock (default 1 s; MPOPIS_COOP_WAIT_US) and the test hook
+// MPOPIS_COOP_TEST_DROP=1: the last workgroup of every cluster leaves at once, i.e. every cluster times out and is redone by the fall-back
+unsigned long long coop_wait_ticks();
+int coop_test_drop();
+
 // kernels_linalg.hip
 size_t potrf_coop_flag_words(int B, int n);
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
-                  unsigned long long* coop_flags = nullptr, unsigned long long* coop_epoch = nullptr);
+                  const CoopCtx& coop = CoopCtx());
 void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
 // kernels_mfma.hip
@@ -170,12 +190,12 @@ void launch_alias_sample(const double* accept, const int32_t* alias, const int32
 // kernels_invsqrt.hip: y = A^-1/2 b (Lanczos + quadrature) and fro = tr(A^-1) = scale * ||L^-1||_F^2 with L = chol(scale * A)
 constexpr size_t kInvsqrtPadDoubles = 512;
 size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot = 1);
-int invsqrt_coop_groups(int B, int n);      // workgroups per matrix the cooperative Lanczos would use for this batch (1: not cooperative)
+int invsqrt_coop_groups(int B, int n, int share = 1);      // workgroups per matrix the cooperative Lanczos would use for this batch (1: not cooperative)
 int invsqrt_max_n();
 void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s);
 void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
                             double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
-                            int regions_per_slot = 1, unsigned long long* coop_xbuf = nullptr, unsigned long long* coop_epoch = nullptr);
+                            int regions_per_slot = 1, const CoopCtx& coop = CoopCtx());
 size_t invsqrt_coop_words(int B, int n);
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
                         double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s);

@@ -119,7 +119,9 @@ int mpopis_handle::ais_update(int n, bool injected) {
             // latency-bound sort / elite mean on the free second stream (beside the rollout it cost the rollout more than it saved)
             if (!fork_recorded) (void)hipEventRecord(ev_fork, stream);          // the Z prefetch may already have marked the point behind the rollout
             (void)hipStreamWaitEvent(xstream[0], ev_fork, 0);
-            launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, xstream[0]);
+            // (no `active` predicate on the side stream: launch_sortperm below clears active[b] for the early break concurrently; an
+            // inactive slot's trace is never consumed, so computing it is merely wasted, deterministic work)
+            launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, nullptr, xstream[0]);
             (void)hipEventRecord(ev_join[0], xstream[0]);
         }
         time_begin(5);
@@ -152,7 +154,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         if (side) (void)hipStreamWaitEvent(stream, ev_join[0], 0);
         else launch_trtri_fro(d_L, (size_t)cs * cs, d_fro_part, B, cs, d_active, stream);
         launch_lanczos_invsqrt(d_Sig, d_sig2, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream,
-                               lan_regions, d_lan_x, &coop_epoch);
+                               lan_regions, lan_coop());
         launch_cma_paths(d_Cdw, d_fro, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
         launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);
         time_end();

@@ -89,9 +89,13 @@ static hipError_t wait_stream(hipStream_t s) {
 
 static int sync_status(mpopis_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
+    if (h->h_coop_timeouts && !h->coop_disabled) HIPCHK(h, hipMemcpyAsync(h->h_coop_timeouts, h->d_coop_timeouts, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, wait_stream(h->stream));
+    // a cluster gave up waiting for a partner (its slot was recomputed by the one-workgroup kernel in the same step, so the results are
+    // complete): this device cannot keep the clusters co-resident right now -- stop using them for this handle instead of paying the wait again
+    if (h->h_coop_timeouts && *h->h_coop_timeouts > 0) h->coop_disabled = true;
     int st = 0;
-    for (int b = 0; b < h->B; ++b) st = std::min(st, h->h_status[b]);
+    for (int b = 0; b < h->B; ++b) st = mpopis::worse_status(st, h->h_status[b]);
     if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
     else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
     else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
@@ -135,14 +139,27 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "bad device ordinal"; return MPOPIS_ERR_ARG; }
     mpopis_handle* h = new mpopis_handle();
     h->cfg = *cfg;
-    HIPCHK((mpopis_handle*)nullptr, hipSetDevice(cfg->device));
-    HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    // a failure half-way (hipStreamCreate under many handles is a realistic one) must not leak the handle and what it already owns
+#define CREATECHK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[512];                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g_create_error = buf_;                                                              \
+            mpopis_destroy(h);                                                                  \
+            return MPOPIS_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+    CREATECHK(hipSetDevice(cfg->device));
+    CREATECHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATECHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < mpopis_handle::kMaxSplit - 1; ++i) {
-        HIPCHK((mpopis_handle*)nullptr, hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
-        HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-        HIPCHK((mpopis_handle*)nullptr, hipEventCreateWithFlags(&h->ev_skew[i], hipEventDisableTiming));
+        CREATECHK(hipStreamCreateWithFlags(&h->xstream[i], hipStreamNonBlocking));
+        CREATECHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        CREATECHK(hipEventCreateWithFlags(&h->ev_skew[i], hipEventDisableTiming));
     }
+#undef CREATECHK
     if (const char* e = getenv("MPOPIS_DEBUG_LAUNCH")) h->debug_launch = atoi(e) != 0;
     if (const char* e = getenv("MPOPIS_NSPLIT")) { h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e))); h->split_auto = false; h->split_pinned = true; }   // experiments / profiling: pins the schedule, mpopis_set_overlap is then ignored
     h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
@@ -165,7 +182,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
     rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn + kInvsqrtPadDoubles); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
     rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
-    rc |= dalloc(h, &h->d_coop_flags, potrf_coop_flag_words(B, cs));
+    rc |= dalloc(h, &h->d_coop_flags, potrf_coop_flag_words(B, cs)); rc |= dalloc(h, &h->d_potrf_redo, B); rc |= dalloc(h, &h->d_lan_redo, B); rc |= dalloc(h, &h->d_coop_timeouts, 1);
     rc |= dalloc(h, &h->d_Z, (size_t)B * cs * K); rc |= dalloc(h, &h->d_E, (size_t)B * cs * K);
     rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);
     rc |= dalloc(h, &h->d_wn, (size_t)B * cs); rc |= dalloc(h, &h->d_mu, (size_t)B * cs); rc |= dalloc(h, &h->d_gvec, (size_t)B * cs);
@@ -193,6 +210,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     h->h_status.assign(B, 0);
     if (hipHostMalloc((void**)&h->h_pin, sizeof(double) * B * (h->as + 2)) != hipSuccess) h->h_pin = nullptr;
+    if (hipHostMalloc((void**)&h->h_coop_timeouts, sizeof(int)) != hipSuccess) h->h_coop_timeouts = nullptr; else *h->h_coop_timeouts = 0;
+    if (const char* e = getenv("MPOPIS_NO_COOP")) h->coop_disabled = atoi(e) != 0;
     // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
     const int n0 = (cfg->policy == MPOPIS_POL_MPPI) ? h->as : cs;
     std::vector<double> eye((size_t)n0 * n0, 0.0);
@@ -220,6 +239,7 @@ void mpopis_destroy(mpopis_handle* h) {
     for (auto st : h->xstream) if (st) (void)hipStreamSynchronize(st);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_coop_timeouts) (void)hipHostFree(h->h_coop_timeouts);
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto st : h->xstream) if (st) (void)hipStreamDestroy(st);
@@ -352,7 +372,7 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     HIPCHK(h, hipMemcpyAsync(h->d_dscale0, ds.data(), sizeof(double) * cs, hipMemcpyHostToDevice, h->stream));
     // factor once: L0 (shared by all slots; the reference refactors the same Σ every call, :307)
     fill_i32(h->d_status, 0, h->B, h->stream);
-    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->d_coop_flags, &h->coop_epoch);
+    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->potrf_coop());
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, wait_stream(h->stream));
     if (h->h_status[0] != 0) { h->err = "PosDefException: Sigma is not positive definite"; return MPOPIS_ERR_NOT_PD; }
@@ -613,7 +633,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
     mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
     mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs, lan_regions)); mv(d_lan_x, (ptrdiff_t)invsqrt_coop_words(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_fro, 1); mv(d_lan_m, 1);
-    mv(d_coop_flags, (ptrdiff_t)potrf_coop_flag_words(1, cs));
+    mv(d_coop_flags, (ptrdiff_t)potrf_coop_flag_words(1, cs)); mv(d_potrf_redo, 1); mv(d_lan_redo, 1);
     mv(alive_gate, 1);
 }
 
@@ -639,6 +659,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     }
     (void)hipEventRecord(ev_fork, stream);                      // the other streams start after everything already queued on the main stream
     hipStream_t main_stream = stream;
+    coop_share = np;                                            // up to np cluster launches in flight at once: each may take 1/np of the device
     int rc = 0, b0 = 0;
     for (int p = 0; p < np; ++p) {
         const int nbp = B0 / np + (p < B0 % np ? 1 : 0);
@@ -650,7 +671,7 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
         if (p > 0) (void)hipEventRecord(ev_join[p - 1], stream);
         shift_slots(nbp); b0 += nbp;
     }
-    shift_slots(-b0); B = B0; stream = main_stream;
+    shift_slots(-b0); B = B0; stream = main_stream; coop_share = 1;
     for (int p = 1; p < np; ++p) (void)hipStreamWaitEvent(stream, ev_join[p - 1], 0);   // later work on the main stream sees every part
     mpc_step += 1;
     if (!rc && !launch_err.empty()) { err = launch_err; launch_err.clear(); return MPOPIS_ERR_HIP; }
@@ -683,7 +704,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         else {
             time_begin(2);
             launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream,
-                         d_coop_flags, &coop_epoch);
+                         potrf_coop());
             time_end();
             Lp = d_L; Lstride = nn;
         }
@@ -724,7 +745,8 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             (void)hipEventRecord(ev_fork, stream);                      // one fork point behind the rollout for both side chains (an event
             fork_recorded = true;                                       // record on the main stream costs ~6 us of its critical path)
             (void)hipStreamWaitEvent(xstream[1], ev_fork, 0);
-            launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, d_active, xstream[1]);
+            // (no `active` predicate: the main stream's sort may clear active[b] concurrently; Z of a slot that stops is simply not consumed)
+            launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, nullptr, xstream[1]);
             (void)hipEventRecord(ev_skew[1], xstream[1]);
             z_prefetched = true;
         }

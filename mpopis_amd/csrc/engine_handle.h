@@ -49,6 +49,11 @@ struct mpopis_handle {
     double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
     unsigned long long* d_coop_flags = nullptr; unsigned long long coop_epoch = 0;         // cooperative Cholesky (cs > 128): panel flags [B][ceil(cs/16)], launch counter
     unsigned long long* d_lan_x = nullptr; int lan_regions = 1;                            // cooperative Lanczos: exchange granules, basis spill regions per slot
+    int *d_potrf_redo = nullptr, *d_lan_redo = nullptr, *d_coop_timeouts = nullptr;         // cooperative kernels that gave up (CoopCtx, engine.h)
+    int* h_coop_timeouts = nullptr; bool coop_disabled = false;                            // pinned mirror of the counter; set after the first time-out
+    int coop_share = 1;                                                                    // multi-stream schedule: that many cluster launches may be in flight at once
+    mpopis::CoopCtx potrf_coop() { mpopis::CoopCtx c; if (!coop_disabled) { c.flags = d_coop_flags; c.epoch = &coop_epoch; c.redo = d_potrf_redo; c.timeouts = d_coop_timeouts; c.share = coop_share; } return c; }
+    mpopis::CoopCtx lan_coop() { mpopis::CoopCtx c; if (!coop_disabled) { c.flags = d_lan_x; c.epoch = &coop_epoch; c.redo = d_lan_redo; c.timeouts = d_coop_timeouts; c.share = coop_share; } return c; }
     int* d_alias_need = nullptr;                                                           // :pmcmppi: slots whose alias table the parallel construction could not certify
     int* d_lan_m = nullptr;                                                                // Lanczos steps taken per slot (diagnostic)
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
@@ -83,6 +88,10 @@ struct mpopis_handle {
 };
 
 namespace mpopis {
+// Error precedence when several slots (or several kernels of one slot) failed in one call: HIP (-4) > ACTION (-3) > NOT_PD (-2) > NUMERIC (-5),
+// i.e. the numeric minimum among the codes of ABI version 1, which the newer MPOPIS_ERR_NUMERIC never hides (include/mpopis.h).
+inline int status_rank(int c) { return c == MPOPIS_ERR_HIP ? 4 : c == MPOPIS_ERR_ACTION ? 3 : c == MPOPIS_ERR_NOT_PD ? 2 : c == MPOPIS_ERR_NUMERIC ? 1 : c < 0 ? 5 : 0; }
+inline int worse_status(int a, int b) { return status_rank(b) > status_rank(a) ? b : a; }
 void launch_scale_rows(double* Z, const double* dsc, int B, int cs, int K, hipStream_t s);
 inline void launch_mppi_Z_in(const double* src, double* dst, int B, int T, int K, int as, hipStream_t s) { launch_transpose_in(src, dst, B * T, as, K, s); }
 inline void launch_mppi_E_out(const double* src, double* dst, int B, int T, int K, int as, hipStream_t s) { launch_transpose_out(src, nullptr, nullptr, dst, B * T, as, K, s); }

@@ -129,7 +129,7 @@ int mpopis_handle::run_trials(int num_steps, int laps, double* records, double* 
             (void)hipMemcpyAsync(h_alive.data(), d_alive, sizeof(int) * B, hipMemcpyDeviceToHost, stream);
             (void)hipMemcpyAsync(h_status.data(), d_status, sizeof(int) * B, hipMemcpyDeviceToHost, stream);
             if (hipStreamSynchronize(stream) != hipSuccess) { err = "stream sync failed"; if (d_actlog) (void)hipFree(d_actlog); return MPOPIS_ERR_HIP; }
-            for (int b = 0; b < B; ++b) worst = std::min(worst, h_status[b]);
+            for (int b = 0; b < B; ++b) worst = mpopis::worse_status(worst, h_status[b]);
             bool any = false;
             for (int b = 0; b < B; ++b) any |= h_alive[b] != 0;
             if (!any || worst) break;

@@ -185,10 +185,18 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                                                                  const double* __restrict__ part, int nb, const double* __restrict__ scale,
                                                                  double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
                                                                  int* __restrict__ msteps, int n, int nvl, int* status, const int* active,
-                                                                 int G, int Gs, unsigned long long* xbuf, unsigned long long epoch) {
+                                                                 int G, int Gs, unsigned long long* xbuf, unsigned long long epoch, int* redo, int* timeouts,
+                                                                 unsigned long long wait_ticks, int test_drop) {
     MPOPIS_HI_PRIO();
     const int b = COOP ? blockIdx.x / G : blockIdx.x, g = COOP ? blockIdx.x % G : 0;
+    if (!COOP && redo) {                                        // fall-back pass behind the cooperative launch: only the slots whose cluster gave up
+        const int r = redo[b];
+        __syncthreads();
+        if (threadIdx.x == 0 && r) redo[b] = 0;
+        if (!r) return;
+    }
     if (active && !active[b]) return;
+    if (COOP && test_drop && g == G - 1) return;                // test hook: a partner that never runs
     extern __shared__ __attribute__((aligned(16))) double sh_lan[];
     const int nc = COOP ? (n + G - 1) / G : 0, c_lo = g * nc, c_hi = min(n, c_lo + nc);       // own columns (COOP)
     double* part_v = sh_lan;                            // [kLanWaves][n]  (COOP: the column slab [nc][n])
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     if (!(nrm_b > 0.0) || !(fro > 0.0)) {                             // δw = 0 -> y = 0; NaN input / unusable trace -> numeric error
         if (writer) {
             for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-            if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) status[b] = MPOPIS_ERR_NUMERIC; }
+            if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) atomicCAS(&status[b], 0, MPOPIS_ERR_NUMERIC); }      // never hides an earlier error of the slot
         }
         return;
     }
@@ -306,14 +314,14 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                     lo = __hip_atomic_load(&xp[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     hi = __hip_atomic_load(&xp[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((lo & 0xffffffff00000000ull) == tlo && (hi & 0xffffffff00000000ull) == thi) break;
-                    if ((++spins & 255u) == 0 && wall_clock64() - t0 > 200000000ull) { timed_out = 1; break; }
+                    if ((++spins & 255u) == 0 && wall_clock64() - t0 > wait_ticks) { timed_out = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const double v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
                 if (idx < n) wv_[idx] = v; else red[kLanWaves + 4 + (idx - n)] = v;
             }
-            if (__syncthreads_or(timed_out)) {
-                if (tid == 0) atomicMin(&status[b], MPOPIS_ERR_HIP);
+            if (__syncthreads_or(timed_out)) {                  // a partner is not running: the one-workgroup kernel queued behind this launch redoes the slot
+                if (tid == 0) { redo[b] = 1; atomicAdd(timeouts, 1); }
                 return;
             }
             if (j == 0) {
@@ -376,7 +384,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             if (!invsqrt_quad_node(mlo, Mhi, lane, 64, &q_shift, &q_weight)) {       // uniform: depends on mlo / Mhi only
                 if (writer) {
                     for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-                    if (tid == 0) { msteps[b] = 0; status[b] = MPOPIS_ERR_NUMERIC; }
+                    if (tid == 0) { msteps[b] = 0; atomicCAS(&status[b], 0, MPOPIS_ERR_NUMERIC); }
                 }
                 return;
             }
@@ -487,43 +495,47 @@ void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int 
 // y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound).
 // xbuf / epoch (nullable): exchange buffer (invsqrt_coop_words, zero-initialised once) and launch counter of the cooperative variant.
 size_t invsqrt_coop_words(int B, int n) { return (size_t)B * 4 * (n + 16); }
-int invsqrt_coop_groups(int B, int n) {
+int invsqrt_coop_groups(int B, int n, int share) {
     static const int env_G = [] { const char* e = getenv("MPOPIS_LANCZOS_G"); return e ? atoi(e) : -1; }();
     int G = env_G >= 0 ? env_G : 8;
     if (G > 16) G = 16;
-    if (G < 2 || n < 160 || n > 1000 || B * G > 128) return 1;                 // small matrices: one CU streams them from L2 fast enough; clusters must be co-resident
+    if (G < 2 || n < 160 || n > 1000 || B * G * share > coop_max_workgroups()) return 1;                 // small matrices: one CU streams them from L2 fast enough; clusters must be co-resident
     const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
     return (fixed + (size_t)4 * n) * sizeof(double) <= 150 * 1024 ? G : 1;
 }
 void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
                             double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
-                            int regions_per_slot, unsigned long long* xbuf, unsigned long long* epoch) {
+                            int regions_per_slot, const CoopCtx& coop) {
     const int nb = (n + kTB - 1) / kTB;
     static std::atomic<unsigned long long> seen2{0}, seen3{0};
-    const int G = (xbuf && epoch) ? std::min(invsqrt_coop_groups(B, n), regions_per_slot) : 1;
+    unsigned long long* const xbuf = coop.flags;
+    const int G = coop.usable() ? std::min(invsqrt_coop_groups(B, n, coop.share), regions_per_slot) : 1;
+    const size_t fixed1 = (size_t)(kLanWaves + 6) * n + 1 + kLanRed + 2 * kLanPivLds * 64;              // doubles (one-workgroup kernel)
+    const int nvl1 = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed1) / n);          // basis vectors that fit next to it
+    const size_t lds1 = (fixed1 + (size_t)nvl1 * n) * sizeof(double);
+    ensure_dyn_lds((const void*)k_lanczos_invsqrt<false>, 150 * 1024, seen2);
     if (G > 1) {
         const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
         const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);
         const size_t lds = (fixed + (size_t)nvl * n) * sizeof(double);
         ensure_dyn_lds((const void*)k_lanczos_invsqrt<true>, 150 * 1024, seen3);
-        const unsigned long long ep = ++*epoch;
+        const unsigned long long ep = ++*coop.epoch;
         if ((ep & 0x3fffffull) == 0) (void)hipMemsetAsync(xbuf, 0, invsqrt_coop_words(B, n) * sizeof(unsigned long long), s);   // tag wrap: no stale granule may alias
         hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl,
-                           status, active, G, regions_per_slot, xbuf, ep);
+                           status, active, G, regions_per_slot, xbuf, ep, coop.redo, coop.timeouts, coop_wait_ticks(), coop_test_drop());
+        // slots whose cluster gave up (bounded waits): recomputed here by the kernel that needs no partner
+        hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl1,
+                           status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, coop.redo, (int*)nullptr, 0ull, 0);
         return;
     }
-    const size_t fixed = (size_t)(kLanWaves + 6) * n + 1 + kLanRed + 2 * kLanPivLds * 64;               // doubles
-    const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);            // basis vectors that fit next to it
-    const size_t lds2 = (fixed + (size_t)nvl * n) * sizeof(double);
-    ensure_dyn_lds((const void*)k_lanczos_invsqrt<false>, 150 * 1024, seen2);
-    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds2, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl,
-                       status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull);
+    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl1,
+                       status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, (int*)nullptr, (int*)nullptr, 0ull, 0);
 }
 
 void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
                         double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
     launch_trtri_fro(L, Lstride, part, B, n, active, s);
-    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s, 1, nullptr, nullptr);
+    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s, 1, CoopCtx());
 }
 
 }  // namespace mpopis

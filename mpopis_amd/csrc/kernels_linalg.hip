@@ -128,13 +128,19 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
 // matrix is the output buffer (L2 resident); the solved panel strip P[m][17] -- both operands of the rank-16 trailing update --
 // lives in LDS, only the trailing read-modify-write goes to L2.  Diagonal blocks and panel solves as in k_potrf_lds.
 __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
-                                                       int n, const double* scale, int* status, int* active) {
+                                                       int n, const double* scale, int* status, int* active, int* redo) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int failed;
     __shared__ DiagScratch dsh;
     constexpr int NTHR = 1024, NW = NTHR / 64, kPS = kNB + 1;
     const int b = blockIdx.x;
+    if (redo) {                                         // fall-back pass behind k_potrf_coop: only the slots whose cluster gave up
+        const int r = redo[b];
+        __syncthreads();
+        if (threadIdx.x == 0 && r) redo[b] = 0;
+        if (!r) return;
+    }
     if (active && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const double* Ab = A + (size_t)b * Astride;
@@ -243,13 +249,15 @@ __device__ __forceinline__ double ld_agent(const double* p) { return __longlong_
 
 __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout, int n, int G, int S,
                                                              const double* scale, int* status, int* active,
-                                                             unsigned long long* flags, unsigned long long epoch) {
+                                                             unsigned long long* flags, unsigned long long epoch, int* redo, int* timeouts,
+                                                             unsigned long long wait_ticks, int test_drop) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ DiagScratch dsh;
     __shared__ int sh_fail, sh_wait, p_off[kCoopMaxOwn], p_ld[kCoopMaxOwn];
     const int b = blockIdx.x / G, g = blockIdx.x % G;
     if (active && !active[b]) return;
+    if (test_drop && g == G - 1) return;                // test hook: a partner that never runs
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int npan = (n + kNB - 1) / kNB, npad = npan * kNB;
     // ownership: blocks of S consecutive panels dealt round-robin; own panel q <-> panel (q / S) S G + g S + q % S
@@ -369,10 +377,10 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
             int st = 0;
             while ((v = __hip_atomic_load(&fl[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ok_val) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 200000000ull) { st = 2; break; }
+                if (wall_clock64() - t0 > wait_ticks) { st = 2; break; }
             }
             if (!st && (v & 1)) st = 1;
-            if (st == 2 && status) atomicMin(&status[b], MPOPIS_ERR_HIP);
+            if (st == 2) { redo[b] = 1; atomicAdd(timeouts, 1); }      // a partner is not running: the slot is recomputed by the one-workgroup kernel queued behind this launch
             sh_wait = st;
         }
         __syncthreads();
@@ -429,8 +437,31 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
 size_t potrf_coop_flag_words(int B, int n) { return (size_t)B * ((n + kNB - 1) / kNB); }
 
 // coop_flags / coop_epoch: per-handle workspace (potrf_coop_flag_words, zero-initialised once) and launch counter; null -> never cooperative
+int coop_max_workgroups() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int v = cus[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 2;
+        v = std::max(1, n);
+        cus[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    static const int env_cap = [] { const char* e = getenv("MPOPIS_COOP_MAX_WG"); return e ? atoi(e) : 0; }();      // tests: pretend a smaller / larger device
+    return env_cap > 0 ? env_cap : v;
+}
+unsigned long long coop_wait_ticks() {
+    static const unsigned long long t = [] { const char* e = getenv("MPOPIS_COOP_WAIT_US"); const long long us = e ? atoll(e) : 1000000ll; return (unsigned long long)std::max(1ll, us) * 100ull; }();
+    return t;
+}
+int coop_test_drop() {
+    static const int v = [] { const char* e = getenv("MPOPIS_COOP_TEST_DROP"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
-                  unsigned long long* coop_flags, unsigned long long* coop_epoch) {
+                  const CoopCtx& coop) {
     const int npad = (n + kNB - 1) / kNB * kNB, npan = npad / kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
@@ -449,7 +480,7 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
     if (G > nblk) G = nblk;
     size_t coop_lds = 0;
     int nown0 = 0;
-    if (G >= 2 && coop_flags && coop_epoch) {
+    if (G >= 2 && coop.usable()) {
         size_t own = 0;                                           // workgroup 0 owns the tallest panels
         for (int q = 0;; ++q) {
             const int c = (q / S) * S * G + (q % S);
@@ -459,19 +490,22 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
         }
         coop_lds = (own + (size_t)npad * kCoopPS) * sizeof(double);
     }
-    // clusters must be co-resident: one workgroup per CU (LDS), keep the grid well below the chip so that kernels of other streams
-    // cannot starve a cluster forever (they finish on their own; every wait is bounded anyway)
-    if (coop_lds && coop_lds <= 150 * 1024 && nown0 <= kCoopMaxOwn && B * G <= 128) {
-        static std::atomic<unsigned long long> seen3{0};
-        ensure_dyn_lds((const void*)k_potrf_coop, 150 * 1024, seen3);
-        const unsigned long long epoch = ++*coop_epoch;
-        hipLaunchKernelGGL(k_potrf_coop, dim3(B * G), dim3(kCoopThreads), coop_lds, s, A, Astride, L, n, G, S, scale, status, active, coop_flags, epoch);
-        return;
-    }
+    // clusters should be co-resident: one workgroup per CU (LDS), the grid at most the device's CU count.  Not assumed: kernels of other
+    // streams / processes may hold CUs, so a cluster that gives up (bounded waits) marks its slot in coop.redo and the one-workgroup kernel
+    // queued right behind recomputes exactly those slots (A is not modified).
     const size_t strip = (size_t)n * (kNB + 1) * sizeof(double);                             // panel strip
     static std::atomic<unsigned long long> seen2{0};
     ensure_dyn_lds((const void*)k_potrf_global, 150 * 1024, seen2);
-    hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active);
+    if (coop_lds && coop_lds <= 150 * 1024 && nown0 <= kCoopMaxOwn && B * G * coop.share <= coop_max_workgroups()) {
+        static std::atomic<unsigned long long> seen3{0};
+        ensure_dyn_lds((const void*)k_potrf_coop, 150 * 1024, seen3);
+        const unsigned long long epoch = ++*coop.epoch;
+        hipLaunchKernelGGL(k_potrf_coop, dim3(B * G), dim3(kCoopThreads), coop_lds, s, A, Astride, L, n, G, S, scale, status, active, coop.flags, epoch,
+                           coop.redo, coop.timeouts, coop_wait_ticks(), coop_test_drop());
+        hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active, coop.redo);
+        return;
+    }
+    hipLaunchKernelGGL(k_potrf_global, dim3(B), dim3(1024), strip, s, A, Astride, L, n, scale, status, active, (int*)nullptr);
 }
 
 // g = Σ⁻¹ (γ U_orig) through the Cholesky factor (Σ symmetric => row vector γ U_orig' Σ⁻¹ = g').

@@ -262,7 +262,7 @@ def test_cooperative_cholesky_cs300(eng_mod, track):
         assert ei.value.code == -2
     eng.close()
     outs = []
-    for B in (2, 24):                                          # 24 x 6 workgroups > the co-residency limit -> k_potrf_global
+    for B in (2, 48):                                          # 48 x 6 workgroups > the device's CUs -> k_potrf_global
         eng = eng_mod.Engine("car", 3, "musigmaaismppi", K * 2, T, batch=B, lam=10.0, ais_its=3, lam_ais=20.0, cov=np.tile([0.0625, 0.1], 3), track=track)
         eng.seed_slots(np.arange(B, dtype=np.uint64) % 2 + 77)
         got = eng.policy_step(None)

@@ -28,7 +28,7 @@ def _num(pattern, text):
 
 @pytest.mark.parametrize("B,n", [(3, 16), (4, 37), (2, 100), (64, 100), (2, 128),          # k_potrf_lds
                                  (3, 129), (2, 145), (4, 200), (8, 300), (2, 333), (2, 384),   # k_potrf_coop, cooperative Lanczos from n = 160
-                                 (24, 300), (2, 400)])                                        # k_potrf_global (grid too large / LDS too small for clusters)
+                                 (24, 300), (48, 300), (2, 400)])                             # 48 x 6 > CUs and n = 400 (LDS too small for clusters): k_potrf_global
 def test_linalg_kernels(harness, B, n):
     r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -46,7 +46,11 @@ int main(int argc, char** argv) {
     printf("B=%d n=%d\n", B, n);
     unsigned long long* dflags; unsigned long long epoch = 0;
     CK(hipMalloc(&dflags, potrf_coop_flag_words(B, n) * 8)); CK(hipMemset(dflags, 0, potrf_coop_flag_words(B, n) * 8));
-    printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s, dflags, &epoch); }, 20, s));
+    int* dredo; CK(hipMalloc(&dredo, (2 * B + 1) * 4)); CK(hipMemset(dredo, 0, (2 * B + 1) * 4));
+    CoopCtx pc; pc.flags = dflags; pc.epoch = &epoch; pc.redo = dredo; pc.timeouts = dredo + 2 * B;
+    CoopCtx lc; lc.flags = dlx; lc.epoch = &lep; lc.redo = dredo + B; lc.timeouts = dredo + 2 * B;
+    if (getenv("KB_NO_COOP")) { pc = CoopCtx(); lc = CoopCtx(); }
+    printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s, pc); }, 20, s));
 #ifdef POTRF_PROF
     {
         std::vector<unsigned long long> pr(8 * 32 * 6); mpopis::debug_read_prof(pr.data());
@@ -72,7 +76,7 @@ int main(int argc, char** argv) {
     if (getenv("KB_LANCZOS_ONCE")) {
         launch_trtri_fro(dL, nn, dpart, B, n, dact, s);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
         hipEventRecord(e1, s); CK(hipStreamSynchronize(s)); float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<int> m1(B), st1(B); CK(hipMemcpy(m1.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st1.data(), dstatus, B * 4, hipMemcpyDeviceToHost));
         printf("one lanczos launch (G = %d): %.3f ms, m[0] = %d, status[0] = %d\n", lanG, ms, m1[0], st1[0]);
@@ -85,11 +89,11 @@ int main(int argc, char** argv) {
         for (int i : {0, 1, 37, 38, 39, 150, 299, 300, 301, 307}) if (i < n + lanG) printf("   x[%d] = %016llx %016llx | parity1 %016llx %016llx\n", i, xb[2 * i], xb[2 * i + 1], xb[2 * (n + lanG) + 2 * i], xb[2 * (n + lanG) + 2 * i + 1]);
         return 0;
     }
-    printf("lanczos (G = %d)       %8.1f us\n", lanG, timeit([&] { launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep); }, 20, s));
+    printf("lanczos (G = %d)       %8.1f us\n", lanG, timeit([&] { launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc); }, 20, s));
     {   // y against the one-workgroup kernel
         std::vector<double> y1((size_t)B * n), y0((size_t)B * n);
         CK(hipMemcpy(y1.data(), dy, y1.size() * 8, hipMemcpyDeviceToHost));
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, 1, nullptr, nullptr);
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, 1, CoopCtx());
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(y0.data(), dy, y0.size() * 8, hipMemcpyDeviceToHost));
         double d = 0, nr = 0; for (size_t i = 0; i < y0.size(); ++i) { d = fmax(d, fabs(y1[i] - y0[i])); nr = fmax(nr, fabs(y0[i])); }
@@ -97,8 +101,8 @@ int main(int argc, char** argv) {
     }
     {   // applying the operator twice must invert A: y2 = A^-1/2 (A^-1/2 b) = A^-1 b  ->  ||A y2 - b|| / ||b||
         double* dy2; CK(hipMalloc(&dy2, (size_t)B * n * 8));
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
-        launch_lanczos_invsqrt(dA, nullptr, dy, n, dpart, dV, dy2, dfro, dm, B, n, dstatus, dact, s, lanG, dlx, &lep);
+        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
+        launch_lanczos_invsqrt(dA, nullptr, dy, n, dpart, dV, dy2, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
         CK(hipStreamSynchronize(s));
         std::vector<double> y2((size_t)B * n); CK(hipMemcpy(y2.data(), dy2, y2.size() * 8, hipMemcpyDeviceToHost));
         double worst = 0;
@@ -119,5 +123,6 @@ int main(int argc, char** argv) {
     std::vector<int> m(B), st(B); std::vector<double> fro(B);
     CK(hipMemcpy(m.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fro.data(), dfro, B * 8, hipMemcpyDeviceToHost));
     printf("   Lanczos steps m = %d %d ..., status %d, tr(A^-1) = %.6e\n", m[0], m[B > 1 ? 1 : 0], st[0], fro[0]);
+    { int to = 0; CK(hipMemcpy(&to, dredo + 2 * B, 4, hipMemcpyDeviceToHost)); printf("   cooperative time-outs (slots redone by the one-workgroup kernels): %d\n", to); }
     return 0;
 }
