@@ -46,6 +46,7 @@ struct mpopis_handle {
     double cma_consts[7] = {0, 0, 0, 0, 0, 0, 0};    // mu_eff, cσ, dσ, cΣ, c1, cμ, E
     std::vector<double> cma_ws_host;
     double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr;
+    double* d_tri_dinv = nullptr;                                                          // [B][ceil(cs/16)][256] diagonal-block inverses of L (k_trtri_diag)
     double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
     unsigned long long* d_coop_flags = nullptr; unsigned long long coop_epoch = 0;         // cooperative Cholesky (cs > 128): panel flags [B][ceil(cs/16)], launch counter
     unsigned long long* d_lan_x = nullptr; int lan_regions = 1;                            // cooperative Lanczos: exchange granules, basis spill regions per slot

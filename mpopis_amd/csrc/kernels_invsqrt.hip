@@ -6,7 +6,7 @@
 //     norm(C * δs[order[ii]])     (:593, δs[..] is a SCALAR through linear indexing)    -- |δ| ||C||_F, i.e. tr(Σ^-1)
 // so the n^3 matrix function (round 1: 16 coupled Newton-Schulz iterations = 48 batched n x n GEMMs per update, 48 % of
 // a C4 step) is replaced by two O(n^2 m) pieces, one workgroup per trial slot / block column:
-//   k_trtri_fro        ||L^-1||_F^2 for the Cholesky factor that the sampler already holds (σ²Σ = L L'):
+//   k_trtri_fro_pair   ||L^-1||_F^2 for the Cholesky factor that the sampler already holds (σ²Σ = L L'):
 //                      tr(Σ^-1) = σ² ||L^-1||_F^2.  Block column J of X = L^-1 depends on L only, so the n/16 block
 //                      columns are independent workgroups; X stays in LDS, only the sum of squares leaves.
 //   k_lanczos_invsqrt  y = Σ^-0.5 δw = ||δw|| V_m f(T_m) e_1: Lanczos with full re-orthogonalisation (CGS2) on Σ,
@@ -42,7 +42,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
 }
 
 constexpr int kTB = 16;                      // block size of the triangular inverse
-constexpr int kInvThreads = 1024, kInvWaves = kInvThreads / 64;
 
 // L(r, c) of the n x n column-major factor, padded with the identity beyond n
 __device__ __forceinline__ double ld_L(const double* __restrict__ L, int n, int r, int c) {
@@ -52,87 +51,125 @@ __device__ __forceinline__ double ld_L(const double* __restrict__ L, int n, int 
 }  // namespace
 
 // part[b][J] = sum of squares of the entries of block column J of L^-1 (rows/cols < n).
-// Block row I of the block column:  X(I) = -L(I,I)^-1 sum_{J <= K < I} L(I,K) X(K).  The chain over I is serial, so each step
-// is kept to ONE global round trip (~1.5 us on this part: a wave batches the 16 loads of its L(I,K) block before using any)
-// and two barriers: the waves split K, apply -L(I,I)^-1 to their own partial product (wave-local, through LDS) and the
-// 16 partial blocks are summed into X(I).  The inverses of all diagonal blocks are formed up front, in parallel over waves.
-__global__ void __launch_bounds__(kInvThreads) k_trtri_fro(const double* __restrict__ Lall, size_t Lstride, int n, int nb, double* __restrict__ part,
-                                                           const int* active) {
+// Block row I of block column J:  X(I) = -L(I,I)^-1 sum_{J <= K < I} L(I,K) X(K).  The chain over I is serial; everything else is arranged
+// so that the chip stays full at large batches AND the chain stays short at one slot:
+//   * the inverses of the diagonal blocks are formed once per slot by a pre-kernel (k_trtri_diag, one wave per block) and live in global memory;
+//   * block column J is paired with block column nb-1-J in one workgroup (W waves each): a pair always holds nb+1 blocks of X, so every
+//     workgroup has the same LDS footprint (48 KB at n = 300: three per CU, all 640 workgroups of 64 slots resident at once) and the same
+//     number of row steps;
+//   * the 16 x 16 block products run on the matrix cores, the L block of the NEXT product / row is requested before the current one is used
+//     (L does not depend on anything computed here), so a row step is 4 MFMAs per K block + one wave-local LDS exchange + two barriers.
+// n = 300: 71 us at 1-8 slots, 100 us at 64 slots (the round-2 kernel -- one 110 KB workgroup of 16 waves per block column, FP64 FMAs from
+// LDS broadcasts -- took 102 us / 313 us alone and 606 us beside the sort on the second stream).
+constexpr int kTriW = 2;                                          // waves per block column
+
+// dinv[b][I][i][k] = (L(I,I)^-1)[i][k], one wave per diagonal block
+__global__ void __launch_bounds__(64) k_trtri_diag(const double* __restrict__ Lall, size_t Lstride, int n, int nb, double* __restrict__ dinv, const int* active) {
     MPOPIS_HI_PRIO();
-    const int b = blockIdx.y, J = blockIdx.x;
+    const int b = blockIdx.y, I = blockIdx.x;
     if (active && !active[b]) return;
-    extern __shared__ __attribute__((aligned(16))) double sh_inv[];
-    const int nbj = nb - J;
-    double* Xs = sh_inv;                               // [nbj][16][16]        block column of X = L^-1 (row-major 16x16 blocks)
-    double* Dall = Xs + (size_t)nbj * 256;             // [nbj][16][16]        Dall[I-J][i][k] = (L(I,I)^-1)[i][k]
-    double* Ws = Dall + (size_t)nbj * 256;             // [kInvWaves][256]     per wave: raw partial product, then (in place) -Dinv * partial
-    double* red = Ws + kInvWaves * 256;                // [kInvWaves]
+    __shared__ double Ld[256], Di[256];
     const double* L = Lall + (size_t)b * Lstride;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = lane & 15, g = lane >> 4;
-    // ---- inverses of the diagonal blocks I = J .. nb-1: wave wv takes I = J + wv, J + wv + 16, ... ------------------------------
-    for (int I = J + wv; I < nb; I += kInvWaves) {
-        double* Ld = Ws + wv * 256;                    // scratch: the diagonal block itself
-        double* Di = Dall + (size_t)(I - J) * 256;
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Ld[i * 16 + 4 * g + q] = ld_L(L, n, 16 * I + i, 16 * I + 4 * g + q);
-        wave_lds_sync();
-        if (lane < 16) {                                // column c of L(I,I)^-1 by forward substitution (rows in order)
-            const int c = lane;
+    for (int q = 0; q < 4; ++q) { Ld[i * 16 + 4 * g + q] = ld_L(L, n, 16 * I + i, 16 * I + 4 * g + q); Di[i * 16 + 4 * g + q] = 0.0; }
+    wave_lds_sync();
+    if (lane < 16) {                                              // column c of L(I,I)^-1 by forward substitution (rows in order)
+        const int c = lane;
 #pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-                double sacc = (r == c) ? 1.0 : 0.0;
+        for (int r = 0; r < 16; ++r) {
+            double sacc = (r == c) ? 1.0 : 0.0;
 #pragma unroll 1
-                for (int k = 0; k < r; ++k) sacc = fma(-Ld[r * 16 + k], Di[k * 16 + c], sacc);   // own column only: program order suffices
-                Di[r * 16 + c] = sacc / Ld[r * 16 + r];
-            }
+            for (int k = 0; k < r; ++k) sacc = fma(-Ld[r * 16 + k], Di[k * 16 + c], sacc);
+            Di[r * 16 + c] = sacc / Ld[r * 16 + r];
         }
-        wave_lds_sync();
     }
-    __syncthreads();
-    for (int e = tid; e < 256; e += kInvThreads) Xs[e] = Dall[e];          // X(J) = L(J,J)^-1
-    __syncthreads();
-    for (int I = J + 1; I < nb; ++I) {
-        const int nact = min(kInvWaves, I - J);                              // waves that own at least one K < I
-        if (wv < nact) {
-            // ---- P_wv = sum_{K = J+wv, J+wv+16, ... < I} L(I,K) X(K);  lane = (row i, column group g): P[i][4g .. 4g+3]
-            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-            for (int K = J + wv; K < I; K += kInvWaves) {
-                double l[16];
+    wave_lds_sync();
+    double* o = dinv + ((size_t)b * nb + I) * 256;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) l[k] = ld_L(L, n, 16 * I + i, 16 * K + k);      // 16 independent loads in flight
-                const double* xk = Xs + (size_t)(K - J) * 256 + 4 * g;
-#pragma unroll 4
-                for (int k = 0; k < 16; ++k) {
-                    p0 = fma(l[k], xk[k * 16 + 0], p0); p1 = fma(l[k], xk[k * 16 + 1], p1);
-                    p2 = fma(l[k], xk[k * 16 + 2], p2); p3 = fma(l[k], xk[k * 16 + 3], p3);
-                }
+    for (int q = 0; q < 4; ++q) o[lane + 64 * q] = Di[lane + 64 * q];
+}
+
+typedef double v4f64_t __attribute__((ext_vector_type(4)));
+
+// Block products on the matrix cores.  __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc) with av = A[li][4kk + lk], bv = Bm[li][4kk + lk]
+// (li = lane & 15, lk = lane >> 4) accumulates acc[r] += sum_k A[li][k] Bm[lk + 4r][k], i.e. acc[r] = (A Bm')[li][lk + 4r] -- the idiom of
+// the Cholesky kernels (kernels_linalg.hip, tile_update).  P = L(I,K) X(K): A = the L block straight from global memory (4 loads per lane
+// and block instead of 16), Bm' = X(K) from LDS (row-major: Bm[j][k] = X[k][j] is the read Xs[(4kk + lk) 16 + li]).
+template <int W>
+__global__ void __launch_bounds__(128 * W) k_trtri_fro_pair(const double* __restrict__ Lall, size_t Lstride, int n, int nb, const double* __restrict__ dinv,
+                                                            double* __restrict__ part, const int* active) {
+    MPOPIS_HI_PRIO();
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    extern __shared__ __attribute__((aligned(16))) double sh_tri[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv / W, wq = wv % W, gt = tid - grp * W * 64;   // group, wave within group, thread within group
+    const int JA = blockIdx.x, JB = nb - 1 - JA;
+    const bool haveB = JB > JA;
+    const int J = grp == 0 ? JA : JB, nbj = nb - J;
+    const bool live = grp == 0 || haveB;
+    double* Xs = sh_tri + (grp == 0 ? 0 : (size_t)(nb - JA) * 256);          // [nbj][16][16] block column of X = L^-1 (row-major blocks)
+    double* Ws = sh_tri + (size_t)(nb + 1) * 256 + (size_t)grp * W * 256;    // [W][256] per wave: raw partial product, then -Dinv * partial
+    double* red = sh_tri + (size_t)(nb + 1) * 256 + (size_t)2 * W * 256;     // [2 W]
+    const double* L = Lall + (size_t)b * Lstride;
+    const double* Db = dinv + (size_t)b * nb * 256;
+    const int li = lane & 15, lk = lane >> 4;
+    if (live) for (int e = gt; e < 256; e += W * 64) Xs[e] = Db[(size_t)J * 256 + e];      // X(J) = L(J,J)^-1
+    // operands of the first row step, requested before the first barrier: they depend on nothing computed here
+    double la[4], da[4];
+    auto load_L = [&](int I, int K, double* dst) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = ld_L(L, n, 16 * I + li, 16 * K + 4 * kk + lk);
+    };
+    auto load_D = [&](int I, double* dst) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = -Db[(size_t)I * 256 + li * 16 + 4 * kk + lk];     // -(L(I,I)^-1)[li][4kk + lk] (zero above the diagonal)
+    };
+    if (live && J + 1 < nb && wq == 0) { load_L(J + 1, J + wq, la); load_D(J + 1, da); }
+    __syncthreads();
+    const int nsteps = nb - JA - 1;                                           // the longer column of the pair
+    for (int st = 0; st < nsteps; ++st) {
+        const int I = J + 1 + st;
+        const bool row = live && I < nb;
+        const int nact = row ? min(W, I - J) : 0;
+        if (wq < nact) {
+            // ---- P = sum_{K = J+wq, J+wq+W, ... < I} L(I,K) X(K), the next block's loads in flight during the MFMAs
+            v4f64_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int K = J + wq; K < I; K += W) {
+                double ln[4] = {0.0, 0.0, 0.0, 0.0};
+                if (K + W < I) load_L(I, K + W, ln);
+                const double* xk = Xs + (size_t)(K - J) * 256;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xk[(4 * kk + lk) * 16 + li], la[kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) la[kk] = ln[kk];
             }
-            double* w = Ws + wv * 256;
-            w[i * 16 + 4 * g + 0] = p0; w[i * 16 + 4 * g + 1] = p1; w[i * 16 + 4 * g + 2] = p2; w[i * 16 + 4 * g + 3] = p3;
+            double* w = Ws + wq * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[li * 16 + lk + 4 * r] = acc[r];      // P[li][lk + 4r]
             wave_lds_sync();
-            // ---- Q_wv = -L(I,I)^-1 P_wv (lower triangular inverse: k <= i)
-            const double* Di = Dall + (size_t)(I - J) * 256 + i * 16;
-            double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
-#pragma unroll 4
-            for (int k = 0; k < 16; ++k) {
-                const double d = (k <= i) ? -Di[k] : 0.0;
-                q0 = fma(d, w[k * 16 + 4 * g + 0], q0); q1 = fma(d, w[k * 16 + 4 * g + 1], q1);
-                q2 = fma(d, w[k * 16 + 4 * g + 2], q2); q3 = fma(d, w[k * 16 + 4 * g + 3], q3);
-            }
+            // ---- Q = -L(I,I)^-1 P
+            v4f64_t q = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) q = __builtin_amdgcn_mfma_f64_16x16x4f64(w[(4 * kk + lk) * 16 + li], da[kk], q, 0, 0, 0);
             wave_lds_sync();                                                  // every lane has read the raw block: overwrite it in place
-            w[i * 16 + 4 * g + 0] = q0; w[i * 16 + 4 * g + 1] = q1; w[i * 16 + 4 * g + 2] = q2; w[i * 16 + 4 * g + 3] = q3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[li * 16 + lk + 4 * r] = q[r];
         }
+        // next row's first operands (global memory, independent of this row's result)
+        if (live && I + 1 < nb && wq < min(W, I + 1 - J)) { load_L(I + 1, J + wq, la); load_D(I + 1, da); }
         __syncthreads();
-        if (tid < 256) {                                                      // X(I) = sum of the waves' Q blocks
-            double sacc = 0.0;
-            for (int w = 0; w < nact; ++w) sacc += Ws[w * 256 + tid];
-            Xs[(size_t)(I - J) * 256 + tid] = sacc;
+        if (row) {
+            for (int e = gt; e < 256; e += W * 64) {                          // X(I) = sum of the waves' blocks
+                double sacc = 0.0;
+                for (int w = 0; w < nact; ++w) sacc += Ws[w * 256 + e];
+                Xs[(size_t)(I - J) * 256 + e] = sacc;
+            }
         }
         __syncthreads();
     }
     double s = 0.0;
-    for (int e = tid; e < nbj * 256; e += kInvThreads) {
+    if (live) for (int e = gt; e < nbj * 256; e += W * 64) {
         const int r = 16 * (J + (e >> 8)) + ((e & 255) >> 4), c = 16 * J + (e & 15);
         const double v = Xs[e];
         if (r < n && c < n) s = fma(v, v, s);
@@ -140,7 +177,7 @@ __global__ void __launch_bounds__(kInvThreads) k_trtri_fro(const double* __restr
     s = wave_sum(s);
     if (lane == 0) red[wv] = s;
     __syncthreads();
-    if (tid == 0) { double t = 0.0; for (int w = 0; w < kInvWaves; ++w) t += red[w]; part[(size_t)b * nb + J] = t; }
+    if (live && gt == 0) { double t = 0.0; for (int w = 0; w < W; ++w) t += red[grp * W + w]; part[(size_t)b * nb + J] = t; }
 }
 
 // Lanczos runs until the error bound is met, at most n steps (with full re-orthogonalisation the Krylov space is then
@@ -190,10 +227,9 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     MPOPIS_HI_PRIO();
     const int b = COOP ? blockIdx.x / G : blockIdx.x, g = COOP ? blockIdx.x % G : 0;
     if (!COOP && redo) {                                        // fall-back pass behind the cooperative launch: only the slots whose cluster gave up
-        const int r = redo[b];
+        if (!redo[b]) return;                                   // (the common case: nothing to do)
         __syncthreads();
-        if (threadIdx.x == 0 && r) redo[b] = 0;
-        if (!r) return;
+        if (threadIdx.x == 0) redo[b] = 0;
     }
     if (active && !active[b]) return;
     if (COOP && test_drop && g == G - 1) return;                // test hook: a partner that never runs
@@ -339,7 +375,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
 #pragma unroll
                     for (int u = 0; u < kLanCG; ++u) {
                         // wave-uniform column base + one lane offset + immediate 512 q: rows past n read into the next column / the
-                        // padding behind the last slot (launch_invsqrt_vec's contract) and are never used
+                        // padding behind the last slot (kInvsqrtPadDoubles, engine.h) and are never used
                         const double* col = A + (size_t)min(c0 + kLanWaves * u, n - 1) * n + r0;
 #pragma unroll
                         for (int q = 0; q < kLanNQ; ++q) a[u][q] = col[lane + 64 * q];
@@ -477,19 +513,21 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
 
 size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot) { return (size_t)B * regions_per_slot * (size_t)(n + 1 + 128) * n; }   // cooperative runs: one spill region per workgroup
 int invsqrt_max_n() {
-    // dynamic LDS of k_lanczos_invsqrt: (kLanWaves + 6) n + ... doubles, and of k_trtri_fro: 32 (n + 15) + 4112 doubles, both <= 150 KiB
-    return std::min((int)((150 * 1024 / 8 - 64 - kLanRed - 2 * kLanPivLds * 64) / (kLanWaves + 8)), (int)((150 * 1024 / 8 - 4112) / 32 - 15));
+    // dynamic LDS of k_lanczos_invsqrt: (kLanWaves + 6) n + ... doubles, and of k_trtri_fro_pair: 16 (n + 31) + 1028 doubles, both <= 150 KiB
+    return std::min((int)((150 * 1024 / 8 - 64 - kLanRed - 2 * kLanPivLds * 64) / (kLanWaves + 8)), (int)((150 * 1024 / 8 - 1028) / 16 - 31));
 }
 
 // y = A^-1/2 b and fro = tr(A^-1) per slot, from A (n x n, SPD) and the Cholesky factor L of scale*A (scale: per-slot, nullable).
 // A must stay readable for kInvsqrtPadDoubles doubles behind its last slot (the mat-vec reads whole 64-row chunks).
 // part[b][nb] = per-block-column partial sums of ||L^-1||_F^2 (only L is read: may run on another stream beside the sort / elite mean)
-void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s) {
+size_t trtri_dinv_doubles(int B, int n) { return (size_t)B * ((n + kTB - 1) / kTB) * 256; }
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv) {
     const int nb = (n + kTB - 1) / kTB;
-    const size_t lds1 = ((size_t)2 * nb * 256 + kInvWaves * 256 + kInvWaves) * sizeof(double);
-    static std::atomic<unsigned long long> seen1{0};
-    ensure_dyn_lds((const void*)k_trtri_fro, 150 * 1024, seen1);
-    hipLaunchKernelGGL(k_trtri_fro, dim3(nb, B), dim3(kInvThreads), lds1, s, L, Lstride, n, nb, part, active);
+    const size_t lds = ((size_t)(nb + 1) * 256 + 2 * kTriW * 256 + 2 * kTriW) * sizeof(double);
+    static std::atomic<unsigned long long> seenp{0};
+    ensure_dyn_lds((const void*)k_trtri_fro_pair<kTriW>, 150 * 1024, seenp);
+    hipLaunchKernelGGL(k_trtri_diag, dim3(nb, B), dim3(64), 0, s, L, Lstride, n, nb, dinv, active);
+    hipLaunchKernelGGL(k_trtri_fro_pair<kTriW>, dim3((nb + 1) / 2, B), dim3(128 * kTriW), lds, s, L, Lstride, n, nb, dinv, part, active);
 }
 
 // y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound).
@@ -530,12 +568,6 @@ void launch_lanczos_invsqrt(const double* A, const double* scale, const double* 
     }
     hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl1,
                        status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, (int*)nullptr, (int*)nullptr, 0ull, 0);
-}
-
-void launch_invsqrt_vec(const double* A, const double* L, size_t Lstride, const double* scale, const double* bvec, size_t bstride,
-                        double* part, double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s) {
-    launch_trtri_fro(L, Lstride, part, B, n, active, s);
-    launch_lanczos_invsqrt(A, scale, bvec, bstride, part, V, y, fro, msteps, B, n, status, active, s, 1, CoopCtx());
 }
 
 }  // namespace mpopis

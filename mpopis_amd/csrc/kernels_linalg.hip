@@ -136,10 +136,9 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
     constexpr int NTHR = 1024, NW = NTHR / 64, kPS = kNB + 1;
     const int b = blockIdx.x;
     if (redo) {                                         // fall-back pass behind k_potrf_coop: only the slots whose cluster gave up
-        const int r = redo[b];
+        if (!redo[b]) return;                           // (the common case: nothing to do)
         __syncthreads();
-        if (threadIdx.x == 0 && r) redo[b] = 0;
-        if (!r) return;
+        if (threadIdx.x == 0) redo[b] = 0;
     }
     if (active && !active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;

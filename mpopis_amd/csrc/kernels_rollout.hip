@@ -8,27 +8,29 @@
 // in ONE launch, state in registers, no per-sample env copies (the reference deep-copies the env
 // per sample, :270).
 //
-// Mapping (CDNA4): lane = sample k, wave = car.  A workgroup is 64 samples x NC cars (NC waves); the
-// cars of one sample exchange (x,y) through LDS once per model step for the pairwise terms of the
-// multi-car reward.  E is [cs][K] (K fastest) so each per-step control load is one coalesced
-// 512-B transaction per wave; the nominal control U, the env state and the 48-point track are
-// wave-uniform and arrive through the scalar cache.  The kernel is FP64-VALU bound;
-// HBM traffic is 8*cs bytes per sample.
+// Mapping (CDNA4): lane = one car of one sample.  One car (k_rollout_car): a wave = 64 samples; E is [cs][K] (K fastest) so
+// each per-step control load is one coalesced 512-B transaction per wave; the nominal control U, the env state and
+// the 48-point track are wave-uniform and arrive through the scalar cache / LDS broadcasts.  NC cars (k_rollout_cars):
+// a wave = 64/NC samples x NC cars, lane = c * S + j, so the cars of one sample sit in ONE wave and exchange (x,y) for
+// the pairwise terms of the multi-car reward by lane shuffles -- no LDS exchange, no barrier in the time loop (round 2
+// ran wave = car with a workgroup barrier per model step: 5.9 cycles per VALU instruction at 64 trials against 4.8
+// for the one-car kernel).  The kernels are FP64-VALU bound; HBM traffic is 8*cs bytes per sample.
 #include "engine.h"
 
 namespace mpopis {
 
-// NC cars x SPB sample-waves per workgroup: the SPB*64 samples of a workgroup share one LDS copy of the track tables
+// One car (NC = 1, CarRacingEnv): SPB sample-waves per workgroup share one LDS copy of the track tables
 // LOG: the trajectory logger is on (a.traj != nullptr) -- only then is the heading angle psi itself tracked
 template <int NC, int SPB, bool LOG>
 __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car(RolloutArgs a) {
+    static_assert(NC == 1, "multi-car envs run k_rollout_cars");
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = (NC > 1) ? wave % NC : 0;                   // car of this wave
-    const int g = wave / NC;                                  // sample group of this wave
+    const int c = 0;                                          // the car
+    const int g = wave;                                       // sample group of this wave
     const int k = (blockIdx.x * SPB + g) * 64 + lane;
     const int K = a.K, T = a.T;
     const bool valid = k < K;
@@ -63,9 +65,6 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
     const double lo0 = a.env.lo[2 * c], hi0 = a.env.hi[2 * c], lo1 = a.env.lo[2 * c + 1], hi1 = a.env.hi[2 * c + 1];
     double* tr = LOG ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
 
-    __shared__ double sh_xy[2][SPB][NC][2][64];
-    __shared__ double sh_cost[SPB][NC][64];
-
     double cost = 0.0, cc = 0.0;
     double e0 = Eb[0], e1 = Eb[K], u0 = Ub[0], u1 = Ub[1];
     for (int t = 0; t < T; ++t) {
@@ -77,20 +76,100 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
         if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V; γ = 0 in every reference config)
         const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
         car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
-        double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
-        if (NC > 1) {                                                          // multi-car_racing.jl:145-158
-            const int buf = t & 1;
-            sh_xy[buf][g][c][0][lane] = s.x;
-            sh_xy[buf][g][c][1][lane] = s.y;
-            __syncthreads();
+        const double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
+        cost -= rew;                                                           // utils.jl:138
+        if (LOG && valid) {                                                    // trajectories[k][t, :] utils.jl:140
+            double s8[8];
+            car_state_to8(s, s8);
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                if (j > c) {
-                    const double dx = sh_xy[buf][g][j][0][lane] - s.x, dy = sh_xy[buf][g][j][1][lane] - s.y;
-                    const double dd = sqrt(dx * dx + dy * dy);
-                    rew += -dd;
-                    if (dd <= 4.0) rew += -11000.0;
-                }
+            for (int i = 0; i < 8; ++i) tr[(size_t)(8 * c + i) * T + t] = s8[i];
+        }
+    }
+    cost += cc;
+    const double total = cost;
+    if (valid) a.cost[(size_t)b * K + k] = total;
+    if (a.cmin) {
+        // ρ = minimum(costs) (utils.jl:81) accumulates here, one atomic per wave, so that the AIS reweighting can be folded into the moments
+        // kernel (launch_wcov_mfma, weights from costs) instead of a launch of its own between the two
+        unsigned long long key = valid ? cost_key(total) : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
+        if (lane == 0) atomicMin(&a.cmin[b], key);
+        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
+    }
+}
+
+// NC >= 2 cars (MultiCarRacingEnv): lane = c * S + j with S = 64 / NC samples per wave, so every car of a sample lives in the same wave.
+// Per-lane (not wave-uniform) here: the start state, the nominal control U (vector loads, one step ahead like E) and the action bounds
+// (LDS table).  The pairwise reward terms (multi-car_racing.jl:145-158) read the other cars' (x, y) by lane shuffles; the sample's cost is
+// the sum over its cars in car order, gathered the same way.  SPB waves per workgroup share one LDS copy of the track tables.
+template <int NC, int SPB, bool LOG, int WPE>
+__global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_rollout_cars(RolloutArgs a) {
+    static_assert(NC >= 2 && NC <= kMaxCars, "2..4 cars");
+    constexpr int S = 64 / NC;                                // samples per wave
+    const int b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = min(lane / S, NC - 1), j = lane - c * S;    // car, sample within the wave (NC = 3: lane 63 idles as a duplicate)
+    const int k = (blockIdx.x * SPB + g) * S + j;
+    const int K = a.K, T = a.T;
+    const bool valid = j < S && k < K;
+    const int kk = min(k, K - 1);
+    constexpr int as = 2 * NC, ss = 8 * NC;
+    (void)ss;
+
+    const CarParams& p = a.env.car;
+    extern __shared__ __attribute__((aligned(16))) double sh_trk[];
+    const int P = a.env.track.P;
+    const int W = a.env.track.nbrw, NS = P * (W + 1);
+    double* sh_nd = sh_trk + 4 * P;                           // neighbour distances [P][W+1]
+    int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);          // neighbour indices   [P][W+1]
+    __shared__ double sh_bnd[NC][4];                          // lo0, hi0, lo1, hi1 per car
+    for (int i = threadIdx.x; i < P; i += 64 * SPB) {
+        sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
+        sh_trk[3 * P + i] = a.env.track.n2[i];
+    }
+    for (int i = threadIdx.x; i < NS; i += 64 * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
+    if (threadIdx.x < NC) {
+        const int q = threadIdx.x;
+        sh_bnd[q][0] = a.env.lo[2 * q]; sh_bnd[q][1] = a.env.hi[2 * q]; sh_bnd[q][2] = a.env.lo[2 * q + 1]; sh_bnd[q][3] = a.env.hi[2 * q + 1];
+    }
+    __syncthreads();
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W};
+    CarState s;
+    {
+        const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
+        s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
+        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+    }
+    const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
+    const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
+    const double* Uo = a.Uorig + (size_t)b * a.cs + 2 * c;
+    const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs + 2 * c : nullptr;
+    double* tr = LOG ? a.traj + ((size_t)b * K + kk) * (size_t)(ss * T) : nullptr;
+
+    double cost = 0.0, cc = 0.0;
+    double e0 = Eb[0], e1 = Eb[K], u0 = Ub[0], u1 = Ub[1];
+    for (int t = 0; t < T; ++t) {
+        const double v0 = u0 + e0, v1 = u1 + e1;                               // V = pol.U + E[:,k]  :271
+        if (t + 1 < T) {                                                       // next step's noise and nominal control in flight during this step
+            e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
+            u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
+        }
+        if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+        const double a0 = clampd(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd(v1, sh_bnd[c][2], sh_bnd[c][3]);   // get_model_controls (NaN passes through)
+        car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
+        double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
+#pragma unroll
+        for (int q = 1; q < NC; ++q) {                                         // multi-car_racing.jl:145-158: the cars behind this one in the env's order
+            const double xq = __shfl(s.x, q * S + j, 64), yq = __shfl(s.y, q * S + j, 64);
+            if (q > c) {
+                const double dx = xq - s.x, dy = yq - s.y;
+                const double dd = sqrt(dx * dx + dy * dy);
+                rew += -dd;
+                if (dd <= 4.0) rew += -11000.0;
             }
         }
         cost -= rew;                                                           // utils.jl:138
@@ -103,25 +182,16 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
     }
     cost += cc;
     double total = cost;
-    bool writer = true;
-    if (NC > 1) {
-        sh_cost[g][c][lane] = cost;
-        __syncthreads();
-        writer = (c == 0);
-        if (c == 0) {
 #pragma unroll
-            for (int j = 1; j < NC; ++j) total += sh_cost[g][j][lane];
-        }
-    }
-    if (writer && valid) a.cost[(size_t)b * K + k] = total;
-    if (a.cmin && writer) {
-        // ρ = minimum(costs) (utils.jl:81) accumulates here, one atomic per wave, so that the AIS reweighting can be folded into the moments
-        // kernel (launch_wcov_mfma, weights from costs) instead of a launch of its own between the two
-        unsigned long long key = valid ? cost_key(total) : ~0ull;
+    for (int q = 1; q < NC; ++q) total += __shfl(cost, q * S + j, 64);         // meaningful on the car-0 lanes: cost_0 + cost_1 + ...
+    const bool writer = valid && c == 0;
+    if (writer) a.cost[(size_t)b * K + k] = total;
+    if (a.cmin) {
+        unsigned long long key = writer ? cost_key(total) : ~0ull;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
         if (lane == 0) atomicMin(&a.cmin[b], key);
-        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
+        if (writer && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
     }
 }
 
@@ -208,21 +278,34 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     }
     const int P = a.env.track.P, W = a.env.track.nbrw;
     const size_t lds = (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int));
-    // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 sample-waves share the LDS tables
+    // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 waves share the LDS tables
     const bool wide = a.K >= 1024;
-    const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B), g2((a.K + 127) / 128, a.B);
+    const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B);
 #define MPOPIS_LAUNCH_CAR(NC, SPB, GRID, BLOCK)                                                        \
     do {                                                                                               \
         if (a.traj) hipLaunchKernelGGL((k_rollout_car<NC, SPB, true>), GRID, dim3(BLOCK), lds, st, a);  \
         else        hipLaunchKernelGGL((k_rollout_car<NC, SPB, false>), GRID, dim3(BLOCK), lds, st, a); \
     } while (0)
+#define MPOPIS_LAUNCH_CARS_W(NC, WPE)                                                                                 \
+    do {                                                                                                              \
+        const int S_ = 64 / NC;                                                                                       \
+        const dim3 gw((a.K + 4 * S_ - 1) / (4 * S_), a.B), gn((a.K + S_ - 1) / S_, a.B);                               \
+        if (wide) { if (a.traj) hipLaunchKernelGGL((k_rollout_cars<NC, 4, true, WPE>), gw, dim3(256), lds, st, a);    \
+                    else        hipLaunchKernelGGL((k_rollout_cars<NC, 4, false, WPE>), gw, dim3(256), lds, st, a); } \
+        else      { if (a.traj) hipLaunchKernelGGL((k_rollout_cars<NC, 1, true, WPE>), gn, dim3(64), lds, st, a);     \
+                    else        hipLaunchKernelGGL((k_rollout_cars<NC, 1, false, WPE>), gn, dim3(64), lds, st, a); }  \
+    } while (0)
+    static const int env_wpe = [] { const char* e = getenv("MPOPIS_CARS_WPE"); return e ? atoi(e) : 3; }();      // waves per SIMD of the multi-car kernel: 3 (168 VGPRs, no spills; 1411 us at 64 three-car trials) beats 4 (128 VGPRs, 33 spills: 1509 us)
+#define MPOPIS_LAUNCH_CARS(NC) do { if (env_wpe == 3) MPOPIS_LAUNCH_CARS_W(NC, 3); else MPOPIS_LAUNCH_CARS_W(NC, 4); } while (0)
     switch (a.env.ncars) {
         case 1: if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64); break;
-        case 2: if (wide) MPOPIS_LAUNCH_CAR(2, 2, g2, 256); else MPOPIS_LAUNCH_CAR(2, 1, g1, 128); break;
-        case 3: MPOPIS_LAUNCH_CAR(3, 1, g1, 192); break;
-        case 4: MPOPIS_LAUNCH_CAR(4, 1, g1, 256); break;
+        case 2: MPOPIS_LAUNCH_CARS(2); break;
+        case 3: MPOPIS_LAUNCH_CARS(3); break;
+        case 4: MPOPIS_LAUNCH_CARS(4); break;
         default: break;
     }
+#undef MPOPIS_LAUNCH_CARS
+#undef MPOPIS_LAUNCH_CARS_W
 #undef MPOPIS_LAUNCH_CAR
 }
 

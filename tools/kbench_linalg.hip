@@ -72,9 +72,10 @@ int main(int argc, char** argv) {
         }
         printf("   potrf max |LL'-A| = %.3e, max |upper| = %.1e\n", err, up);
     }
-    printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s); }, 20, s));
+    double* ddinv; CK(hipMalloc(&ddinv, trtri_dinv_doubles(B, n) * 8));
+    printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv); }, 20, s));
     if (getenv("KB_LANCZOS_ONCE")) {
-        launch_trtri_fro(dL, nn, dpart, B, n, dact, s);
+        launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
         launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
         hipEventRecord(e1, s); CK(hipStreamSynchronize(s)); float ms; hipEventElapsedTime(&ms, e0, e1);
