@@ -648,7 +648,11 @@ int mpopis_handle::policy_step_enqueue(bool injected) {
     // (Cholesky 61 -> 29 us) it is worth 1-3 % at >= 64 K=4096-trials and nothing below (ms per step at 1 / 2 / 3 / 4 parts: 32 trials
     // 3.87 / 3.76 / 3.84 / 4.19, 64 trials 6.52 / 6.46 / 6.45 / 6.35, 128 trials 12.08 / 11.91 / 11.79 / 11.67), at the price of per-kernel
     // durations that include time-sharing -- opt-in.
-    const int np = split_auto ? 1 : std::min(nsplit, B0);
+    // Exception to the default: :cmamppi with cs > 128 at >= 48 resident slots.  There the per-slot Cholesky / Lanczos kernels (one workgroup
+    // per slot: 64 of 256 CUs busy for ~540 us per iteration) are 19 % of the step, and four part-chains put them under the other parts'
+    // rollouts: C4 at 64 trials 28.6 -> 26.9 ms per step (32 trials: no gain, 16.6 vs 16.9).
+    const int auto_np = (cfg.policy == MPOPIS_POL_CMAMPPI && cs > 128 && B0 >= 48) ? 4 : 1;
+    const int np = split_auto ? auto_np : std::min(nsplit, B0);
     if (np < 2) {
         side_free = (xstream[0] != nullptr);
         const int rc = step_enqueue_view(injected, nullptr, nullptr);

@@ -761,6 +761,18 @@ static void cov_common_cols(int cs, int m, const double *X, double *mean, double
             S[a + (size_t)b * cs] = (1 - lam) * S[a + (size_t)b * cs] + ((a == b) ? lam * f : 0.0);
 }
 
+int orc_cov_estimate(int cs, int m, const double *X, int est, double *mean, double *S) {
+    if (cs < 1 || m < 2 || !X || !mean || !S) return -1;
+    switch (est) {
+        case ORC_SIGMA_EST_MLE: cov_mle_cols(cs, m, X, mean, S); return 0;
+        case ORC_SIGMA_EST_SS: cov_ss_cols(cs, m, X, mean, S); return 0;
+        case ORC_SIGMA_EST_LW: cov_lw_cols(cs, m, X, mean, S); return 0;
+        case ORC_SIGMA_EST_RBLW: cov_common_cols(cs, m, X, mean, S, 0); return 0;
+        case ORC_SIGMA_EST_OAS: cov_common_cols(cs, m, X, mean, S, 1); return 0;
+        default: return -1;
+    }
+}
+
 /* [3P] StatsBase 0.34 src/cov.jl: mean_and_cov(x::DenseMatrix, w::AbstractWeights, dims = 2; corrected = false):
  * m = mean(x, w, dims = 2); scattermat(x, w, mean = m, dims = 2) / sum(w)   (policies.jl:730-733) */
 static void wmean_wcov(int cs, int K, const double *E, const double *w, double *mu, double *S) {

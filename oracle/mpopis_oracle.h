@@ -86,6 +86,10 @@ void   orc_inv_from_chol(int n, const double *L, double *Ainv);
 int    orc_sym_eig(int n, const double *A, double *evals, double *V); /* cyclic Jacobi */
 int    orc_sym_pow(int n, const double *A, double p, double *out);    /* V diag(l^p) V' */
 
+/* cov(Σ_est, elite') as CEMPPI calls it (src/mppi_mpopi_policies.jl:464; X = cs x m col-major, est = ORC_SIGMA_EST_*): the estimator
+ * alone, exported so that tests can check each third-party block against an independent implementation (tests/test_third_party_blocks.py) */
+int    orc_cov_estimate(int cs, int m, const double *X, int est, double *mean, double *S);
+
 /* ---- RNG used by BOTH the oracle and the engine for synthetic runs (Philox4x32-10) ------ */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void   orc_philox_normals(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi,

@@ -380,6 +380,20 @@ def sym_pow(A, p):
     return rc, o.reshape(n, n).T.copy()
 
 
+SIGMA_EST = {"mle": 0, "ss": 1, "lw": 2, "rblw": 3, "oas": 4}
+
+
+def cov_estimate(X, est):
+    """cov(Σ_est, X') for X of shape (cs, m) (columns = observations, like the elite matrix :464) -> (mean, S)."""
+    X = np.asarray(X, dtype=np.float64)
+    cs, m = X.shape
+    Xf = np.ascontiguousarray(X.T)                       # cs x m column-major
+    mean, S = np.zeros(cs), np.zeros(cs * cs)
+    rc = lib().orc_cov_estimate(cs, m, _d(Xf), SIGMA_EST[est], _d(mean), _d(S))
+    assert rc == 0
+    return mean, S.reshape(cs, cs).T.copy()
+
+
 def block_diagm(A, rep):
     A = np.asarray(A, dtype=np.float64)
     if A.ndim == 1:

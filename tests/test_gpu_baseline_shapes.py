@@ -162,6 +162,11 @@ def test_C4_cmamppi_3car_device_rng_N4(eng_mod, oracle, track):
     run_case(eng_mod, oracle, track, "cmamppi", 3, 4096, 50, 4, B=1, steps=2, device_rng=True)
 
 
+def test_C4_cmamppi_3car_N10_harness_default(eng_mod, oracle, track):
+    """configs[3] with the harness' ais_its = 10 (src/examples/car_example.jl:63), one trial, one MPC step, device RNG."""
+    run_case(eng_mod, oracle, track, "cmamppi", 3, 4096, 50, 10, B=1, steps=1, device_rng=True)
+
+
 def test_C5_musigma_K4096_H50_N10_injected(eng_mod, oracle, track):
     run_case(eng_mod, oracle, track, "musigmaaismppi", 1, 4096, 50, 10, steps=1)
 

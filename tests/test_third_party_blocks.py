@@ -1,0 +1,115 @@
+"""Independent checks of the third-party blocks the reference's DEFAULT configurations run through, with what this image has
+(NumPy / SciPy / scikit-learn) -- Julia is absent, so these do not pin the oracle to the reference (tools/gen_golden.jl does, once run);
+they pin the oracle's C code to a second, separately written implementation of the formula its header names:
+
+  LinearShrinkage(DiagonalUnequalVariance(), :ss)   src/mppi_mpopi_policies.jl:419, harness default src/examples/car_example.jl:66
+      Schaefer & Strimmer (2005), "A shrinkage approach to large-scale covariance matrix estimation ...", Stat. Appl. Genet. Mol. Biol. 4(1),
+      Table 1 target D + eq. (10)/Appendix: lambda* = sum_{i != j} Var^(r_ij) / sum_{i != j} r_ij^2 on standardised data,
+      Var^(r_ij) = n / (n-1)^3 sum_k (w_kij - wbar_ij)^2, w_kij = z_ki z_kj
+  LinearShrinkage(DiagonalUnequalVariance(), :lw)   :417      the same intensity on the unstandardised data (Ledoit & Wolf 2003 style)
+  LinearShrinkage(DiagonalCommonVariance(), :rblw / :oas)   :421-423
+      Chen, Wiesel, Eldar & Hero (2010), "Shrinkage algorithms for MMSE covariance estimation", IEEE TSP 58(10), eqs. (17) and (23);
+      scikit-learn's OAS implements eq. (23) without the 2/p terms (its own source comment), same target F = tr(S)/p I
+  Σ^-0.5 (LinearAlgebra: symmetric eigen-decomposition) :580   scipy.linalg.fractional_matrix_power / eigh
+  cholesky(Σ) (PDMats) :447                                    numpy.linalg.cholesky
+"""
+import numpy as np
+import pytest
+
+
+def _elite(cs, m, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((cs, cs)) * 0.2 + np.diag(np.tile([0.25, 0.32], cs // 2 + 1)[:cs])
+    return A @ rng.standard_normal((cs, m)) + rng.standard_normal((cs, 1))
+
+
+def _offdiag_lambda(S_shrunk, S):
+    """shrinkage intensity recovered from an estimate whose off-diagonals are (1 - lambda) S_ij"""
+    mask = ~np.eye(S.shape[0], dtype=bool) & (np.abs(S) > 1e-3 * np.abs(S).max())
+    r = 1.0 - S_shrunk[mask] / S[mask]
+    assert np.ptp(r) < 1e-10, "not a single linear shrinkage of the off-diagonals"
+    return float(r.mean())
+
+
+def np_schaefer_strimmer(X, standardise):
+    cs, n = X.shape
+    Xc = X - X.mean(axis=1, keepdims=True)
+    S = Xc @ Xc.T / n
+    Z = Xc / np.sqrt(np.diag(S))[:, None] if standardise else Xc
+    R = Z @ Z.T / n                                            # wbar_ij (= r_ij when standardised)
+    W2 = (Z ** 2) @ (Z ** 2).T / n                             # mean_k w_kij^2
+    var = (W2 - R ** 2) * n * (n / (n - 1.0) ** 3)             # n/(n-1)^3 sum_k (w - wbar)^2
+    off = ~np.eye(cs, dtype=bool)
+    lam = min(1.0, max(0.0, var[off].sum() / (R[off] ** 2).sum()))
+    out = S * (1.0 - lam)
+    out[np.diag_indices(cs)] = np.diag(S)
+    return lam, out, S
+
+
+@pytest.mark.parametrize("cs,m", [(100, 30), (20, 50), (300, 819)])
+@pytest.mark.parametrize("est,standardise", [("ss", True), ("lw", False)])
+def test_unequal_variance_shrinkage_against_numpy(oracle, cs, m, est, standardise):
+    X = _elite(cs, m, cs + m)
+    mean, S_o = oracle.cov_estimate(X, est)
+    lam, S_np, S = np_schaefer_strimmer(X, standardise)
+    assert np.allclose(mean, X.mean(axis=1), rtol=0, atol=1e-13)
+    assert np.allclose(np.diag(S_o), np.diag(S), rtol=1e-12)                   # target D: the variances are not shrunk
+    assert 0.0 < lam < 1.0
+    assert abs(_offdiag_lambda(S_o, S) - lam) < 1e-10
+    assert np.max(np.abs(S_o - S_np)) < 1e-12 * np.abs(S).max()
+
+
+@pytest.mark.parametrize("cs,m", [(100, 30), (20, 50), (300, 819)])
+def test_common_variance_shrinkage_against_paper_and_sklearn(oracle, cs, m):
+    from sklearn.covariance import OAS, empirical_covariance
+    X = _elite(cs, m, 7 * cs + m)
+    S = empirical_covariance(X.T)                                              # MLE, centred
+    p, n = float(cs), float(m)
+    tr, tr2 = np.trace(S), np.sum(S * S)
+    lam_oas = min(1.0, ((1 - 2 / p) * tr2 + tr ** 2) / ((n + 1 - 2 / p) * (tr2 - tr ** 2 / p)))            # eq. (23)
+    lam_rblw = min(1.0, ((n - 2) / n * tr2 + tr ** 2) / ((n + 2) * (tr2 - tr ** 2 / p)))                  # eq. (17)
+    for est, lam in (("oas", lam_oas), ("rblw", lam_rblw)):
+        _, S_o = oracle.cov_estimate(X, est)
+        ref = (1 - lam) * S + lam * tr / p * np.eye(cs)
+        assert np.max(np.abs(S_o - ref)) < 1e-12 * np.abs(S).max(), est
+    sk = OAS().fit(X.T)
+    # scikit-learn drops the 2/p terms of eq. (23): same structure, intensity equal up to O(1/p)
+    assert abs(sk.shrinkage_ - lam_oas) < 3.0 / p
+    _, S_o = oracle.cov_estimate(X, "oas")
+    lam_o = 1.0 - (S_o[0, 1] / S[0, 1])
+    assert np.max(np.abs(S_o - ((1 - lam_o) * S + lam_o * tr / p * np.eye(cs)))) < 1e-12 * np.abs(S).max()
+    assert np.max(np.abs(sk.covariance_ - ((1 - sk.shrinkage_) * S + sk.shrinkage_ * tr / p * np.eye(cs)))) < 1e-12
+
+
+@pytest.mark.parametrize("n,cond", [(8, 1e1), (100, 1e3), (300, 1e5)])
+def test_sym_pow_and_cholesky_against_scipy(oracle, n, cond):
+    import scipy.linalg as sla
+    rng = np.random.default_rng(n)
+    Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    A = (Q * (0.1 * np.logspace(0, -np.log10(cond), n))) @ Q.T
+    A = 0.5 * (A + A.T)
+    rc, C = oracle.sym_pow(A, -0.5)
+    assert rc == 0
+    w, V = np.linalg.eigh(A)
+    ref = (V / np.sqrt(w)) @ V.T
+    assert np.max(np.abs(C - ref)) < 1e-9 * np.abs(ref).max()
+    if n <= 100:                                                               # the Schur-based general routine: slower, an independent algorithm
+        ref2 = np.real(sla.fractional_matrix_power(A, -0.5))
+        assert np.max(np.abs(C - ref2)) < 1e-7 * np.abs(ref2).max()
+    assert np.max(np.abs(C @ C @ A - np.eye(n))) < 1e-8 * cond
+    rc, L = oracle.cholesky_lower(A)
+    assert rc == 0 and np.max(np.abs(L - np.linalg.cholesky(A))) < 1e-12
+
+
+def test_alias_table_is_a_valid_table_of_the_weights(oracle):
+    """StatsBase.make_alias_table! (:804-805): whatever the pairing order, a valid alias table reproduces the weights:
+    p_i = (accept_i + sum_{j : alias_j = i} (1 - accept_j)) / K."""
+    rng = np.random.default_rng(5)
+    for K in (7, 150, 4096):
+        w = np.exp(-rng.exponential(2.0, K) * rng.uniform(0.5, 8.0))
+        w /= w.sum()
+        acc, al = oracle.make_alias_table(w)
+        p = acc.copy()
+        np.add.at(p, al, 1.0 - acc)
+        assert np.max(np.abs(p / K - w)) < 1e-13
+        assert np.all((acc >= 0) & (acc <= 1 + 1e-12)) and np.all((al >= 0) & (al < K))
