@@ -73,6 +73,10 @@ struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[
     // optional neighbour tables for the anchored nearest-point search (nullptr => always full scan):
     // row i = the nbrw points closest to q_i in ascending distance (rank 0 = i itself), row stride nbrw + 1
     const int* nbr_idx; const double* nbr_dist; int nbrw;
+    // optional ring table for the straight-line fast path of the rollout kernels (nullptr => within_track only): entry e, -2 <= e <= P+1,
+    // at ring[4 (e + 2) .. 4 (e + 2) + 3] = {x, y, |q|^2, lane_width} of track point e mod P -- the ring neighbours of any point are then at
+    // fixed offsets (no wrap-around index arithmetic); ring_cert[i] = ring_r2[i] (see below)
+    const double* ring = nullptr; const double* ring_cert = nullptr;
 };
 constexpr int kTrackNbrW = 16;
 // Row i of nbr_dist has one spare slot (index nbrw): it holds ring_r2[i] = (1 - 1e-9) x the squared distance from q_i to the nearest
@@ -85,6 +89,8 @@ constexpr int kTrackNbrW = 16;
 #include <utility>
 #include <vector>
 namespace mpopis {
+// host: ring table (see Track::ring) and certification radii from the neighbour table
+inline void build_track_ring(int P, const double* x, const double* y, const double* w, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert);
 // host: neighbour tables of the anchored nearest-point search (row stride W + 1, see Track) for P points; W = min(kTrackNbrW, P)
 inline void build_track_tables(int P, const double* x, const double* y, std::vector<double>& nd, std::vector<int>& ni) {
     const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
@@ -100,6 +106,16 @@ inline void build_track_tables(int P, const double* x, const double* y, std::vec
         for (int j = 0; j < P; ++j) if (j != i && j != im && j != ip) r2 = fmin(r2, (x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i]));
         nd[(size_t)i * S + W] = r2 * (1.0 - 1e-9);
     }
+}
+inline void build_track_ring(int P, const double* x, const double* y, const double* w, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert) {
+    const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
+    ring.assign((size_t)(P + 4) * 4, 0.0); cert.assign((size_t)P, 0.0);
+    for (int e = -2; e <= P + 1; ++e) {
+        const int i = ((e % P) + P) % P;
+        double* o = ring.data() + (size_t)(e + 2) * 4;
+        o[0] = x[i]; o[1] = y[i]; o[2] = x[i] * x[i] + y[i] * y[i]; o[3] = w[i];
+    }
+    for (int i = 0; i < P; ++i) cert[i] = nd[(size_t)i * S + W];
 }
 
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
@@ -372,6 +388,25 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     c.sp = sp; c.cp = cp; c.sd = sd; c.cd = cd;
 }
 
+// Tail of within_track (car_racing_tracks.jl:75-90): nearest point p1 with its ring predecessor pm / successor pp -> distance of p from the
+// line through p1 and the nearer of the two, and the lane test.  Shared by the general search and the ring fast path (identical arithmetic,
+// so a rollout's cost does not depend on which of the two found the nearest point).
+MP_HD bool track_project(double px, double py, double p1x, double p1y, double pmx, double pmy, double ppx, double ppy, double lane_w, double* dist_out) {
+    const double ax = pmx - px, ay = pmy - py, bx = ppx - px, by = ppy - py;
+    // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone).  Only when the two squares
+    // differ by an ulp or two could the rounding of the reference's square roots turn `>` into its tie (-> prev); at that
+    // point the position is equidistant from both neighbours to 1e-16 and the reference's own choice is rounding noise.
+    const double dm2 = fma(ax, ax, ay * ay), dp2 = fma(bx, bx, by * by);
+    const bool prev = dm2 <= dp2;
+    const double p2x = prev ? pmx : ppx, p2y = prev ? pmy : ppy;
+    const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
+    const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
+    const double ex = (p1x + t * vx) - px, ey = (p1y + t * vy) - py;           // :88-89
+    const double dist = fast_sqrt(ex * ex + ey * ey);
+    *dist_out = dist;
+    return dist < lane_w;                                                      // :90
+}
+
 // within_track(track, pos): car_racing_tracks.jl:68-92.
 // findmin over |q_i - p|^2 (:71-73) is evaluated as v_i = |q_i|^2 - 2 q_i.p (|p|^2 is common to all i): 2 FMAs per
 // point; near-ties (< 1e-10 m^2 apart) may resolve differently from the literal form, which is harmless (the two
@@ -435,19 +470,30 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
         const int ip = (mi == tk.P - 1) ? 0 : mi + 1;
         p1x = tk.x[mi]; p1y = tk.y[mi]; pmx = tk.x[im]; pmy = tk.y[im]; ppx = tk.x[ip]; ppy = tk.y[ip];
     }
-    const double ax = pmx - px, ay = pmy - py, bx = ppx - px, by = ppy - py;
-    // :77-79 `dist(prev) <= dist(next)` decided on the squared distances (sqrt is monotone).  Only when the two squares
-    // differ by an ulp or two could the rounding of the reference's square roots turn `>` into its tie (-> prev); at that
-    // point the position is equidistant from both neighbours to 1e-16 and the reference's own choice is rounding noise.
-    const double dm2 = fma(ax, ax, ay * ay), dp2 = fma(bx, bx, by * by);
-    const bool prev = dm2 <= dp2;
-    const double p2x = prev ? pmx : ppx, p2y = prev ? pmy : ppy;
-    const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
-    const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
-    const double ex = (p1x + t * vx) - px, ey = (p1y + t * vy) - py;           // :88-89
-    const double dist = fast_sqrt(ex * ex + ey * ey);
-    *dist_out = dist;
-    return dist < tk.w[mi];                                                    // :90
+    return track_project(px, py, p1x, p1y, pmx, pmy, ppx, ppy, tk.w[mi], dist_out);
+}
+
+// Straight-line fast path of the nearest-point search for the rollout kernels (anchor = the previous step's nearest point, ring table in LDS).
+// Applies when the anchor's certification holds (the nearest point is one of {a0-1, a0, a0+1}, see Track) and the three candidate distances
+// are pairwise different (no tie to break by index): then the argmin is two comparisons, its ring neighbours sit at fixed offsets of the padded
+// table, and no index arithmetic, list scan or point permutation is needed.  Returns false when it does not apply (first step, NaN position,
+// far from the anchor, exact ties): the caller then runs within_track, which finds the same point by the general rules -- and both end in
+// track_project, so the result never depends on the path taken.  rel (out) = nearest point - anchor in ring steps (-1, 0, +1).
+MP_HD bool ring_candidates(const double* ring, const double* cert, int a0, double px, double py, int* rel) {
+    const int a = a0 < 0 ? 0 : a0;                                             // branch-free: a missing anchor reads entry 0 and reports "not applicable"
+    const double* e0 = ring + (size_t)4 * (a + 2);
+    const double m2x = -2.0 * px, m2y = -2.0 * py;
+    const double d0 = fma(e0[1], m2y, fma(e0[0], m2x, e0[2]));                 // |q|^2 - 2 q.p, as in within_track
+    const double dm = fma(e0[-3], m2y, fma(e0[-4], m2x, e0[-2]));
+    const double dp = fma(e0[5], m2y, fma(e0[4], m2x, e0[6]));
+    const double D02 = d0 + fma(px, px, py * py);
+    const bool ok = (a0 >= 0) & (4.0 * D02 < cert[a]) & (d0 != dm) & (d0 != dp) & (dm != dp);
+    *rel = (dm < d0 && dm < dp) ? -1 : ((dp < d0 && dp < dm) ? 1 : 0);
+    return ok;
+}
+MP_HD bool ring_project(const double* ring, int a0, int rel, double px, double py, double* dist_out) {
+    const double* e = ring + (size_t)4 * (a0 + rel + 2);
+    return track_project(px, py, e[0], e[1], e[-4], e[-3], e[4], e[5], e[3], dist_out);
 }
 
 // reward(env::CarRacingEnv): src/envs/car_racing.jl:201-213
@@ -457,9 +503,29 @@ MP_HD bool exceed_beta(const CarParams& p, double Vx, double Vy) {
     return (Vx < 0.0) && (fabs(Vy) < p.tan_blim * (-Vx));
 }
 
+// all lanes of the wave agree (device) / the single caller (host)
+MP_HD bool wave_all(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(v);
+#else
+    return v;
+#endif
+}
+
 MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y, double Vx, double Vy, int* anchor = nullptr) {
     double dist;
-    const bool within = within_track(tk, x, y, &dist, anchor);
+    bool within;
+    int rel = 0;
+    // rollout kernels (anchor carried, ring table staged): one wave-uniform branch -- every lane on the straight-line path, or the whole
+    // wave through the general search (first step of a rollout, a lane far off its anchor, exact ties)
+    const bool fast = tk.ring && anchor && ring_candidates(tk.ring, tk.ring_cert, *anchor, x, y, &rel);
+    if (__builtin_expect(tk.ring && anchor && wave_all(fast), 1)) {
+        within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
+        const int mi = *anchor + rel;
+        *anchor = (mi < 0) ? tk.P - 1 : ((mi >= tk.P) ? 0 : mi);
+    } else {
+        within = within_track(tk, x, y, &dist, anchor);
+    }
     double rew = 0.0;
     if (!within) rew += -1000000.0;
     if (exceed_beta(p, Vx, Vy)) rew += -5000.0;                                // exceed_β :184-189

@@ -125,7 +125,8 @@ void launch_env_query(const EnvDesc& env, const double* x, const int* done, doub
 
 // kernels_sample.hip
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
-                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s);
+                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s, const double* rng_tab);
+void launch_rng_tab_init(double* gtab, hipStream_t s);      // philox.h: kRngTabDoubles doubles (Box-Muller tables), once per handle
 void launch_sample_resample_draws(int32_t* di, double* du, int B, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                                   const int* active, hipStream_t s);
 
@@ -152,15 +153,18 @@ int coop_test_drop();
 
 // kernels_linalg.hip
 size_t potrf_coop_flag_words(int B, int n);
+// panel (nullable, n <= kPanelRows): second copy of the factor in the staging layout of the fused sampler (potrf_panel_doubles(n) per slot)
+constexpr int kPanelRows = 128;
+size_t potrf_panel_doubles(int n);
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
-                  const CoopCtx& coop = CoopCtx());
+                  const CoopCtx& coop = CoopCtx(), double* panel = nullptr, size_t pstride = 0);
 void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
 // kernels_mfma.hip
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
 bool sample_trmm_fusable(int n);
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                              const int* active, hipStream_t s);
+                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,

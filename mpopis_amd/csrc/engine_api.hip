@@ -174,7 +174,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     default_mc_params(p); h->env.mc = make_mc_params(p);
     default_cp_params(p); h->env.cp = make_cp_params(p);
     for (int i = 0; i < kMaxAs; ++i) { h->env.lo[i] = -1.0; h->env.hi[i] = 1.0; }
-    h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
+    h->env.track = Track{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr};
     const int B = h->B, K = h->K, cs = h->cs;
     const size_t nn = (size_t)cs * cs;
     int rc = 0;
@@ -182,6 +182,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_U, (size_t)B * cs); rc |= dalloc(h, &h->d_Ucur, (size_t)B * cs); rc |= dalloc(h, &h->d_Uin, (size_t)B * cs);
     rc |= dalloc(h, &h->d_Sigma0, nn); rc |= dalloc(h, &h->d_Sig, (size_t)B * nn + kInvsqrtPadDoubles); rc |= dalloc(h, &h->d_L, (size_t)B * nn);
     rc |= dalloc(h, &h->d_L0, nn); rc |= dalloc(h, &h->d_tmpS, (size_t)B * nn);
+    if (sample_trmm_fusable(cs)) { rc |= dalloc(h, &h->d_L0p, potrf_panel_doubles(cs)); rc |= dalloc(h, &h->d_Lp, (size_t)B * potrf_panel_doubles(cs)); }
     rc |= dalloc(h, &h->d_coop_flags, potrf_coop_flag_words(B, cs)); rc |= dalloc(h, &h->d_potrf_redo, B); rc |= dalloc(h, &h->d_lan_redo, B); rc |= dalloc(h, &h->d_coop_timeouts, 1);
     rc |= dalloc(h, &h->d_Z, (size_t)B * cs * K); rc |= dalloc(h, &h->d_E, (size_t)B * cs * K);
     rc |= dalloc(h, &h->d_cost, (size_t)B * K); rc |= dalloc(h, &h->d_w, (size_t)B * K);
@@ -189,7 +190,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_dscale, (size_t)B * cs); rc |= dalloc(h, &h->d_dscale0, (size_t)cs);
     rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B); rc |= dalloc(h, &h->d_wsum, B); rc |= dalloc(h, &h->d_cmin, B);
     rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
-    rc |= dalloc(h, &h->d_seeds, B);
+    rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, 2 * (128 + 64));
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
@@ -208,6 +209,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     }
     if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
+    launch_rng_tab_init(h->d_rng_tab, h->stream);
     h->h_status.assign(B, 0);
     if (hipHostMalloc((void**)&h->h_pin, sizeof(double) * B * (h->as + 2)) != hipSuccess) h->h_pin = nullptr;
     if (hipHostMalloc((void**)&h->h_coop_timeouts, sizeof(int)) != hipSuccess) h->h_coop_timeouts = nullptr; else *h->h_coop_timeouts = 0;
@@ -283,8 +285,14 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     if (dalloc(h, &dnd, nd.size()) || dalloc(h, &dni, ni.size())) return MPOPIS_ERR_HIP;
     HIPCHK(h, hipMemcpyAsync(dnd, nd.data(), sizeof(double) * nd.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dni, ni.data(), sizeof(int) * ni.size(), hipMemcpyHostToDevice, h->stream));
+    std::vector<double> ring, cert;
+    build_track_ring(P, x, y, w, nd, ring, cert);
+    double* dring = nullptr;
+    if (dalloc(h, &dring, ring.size() + cert.size())) return MPOPIS_ERR_HIP;
+    HIPCHK(h, hipMemcpyAsync(dring, ring.data(), sizeof(double) * ring.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dring + ring.size(), cert.data(), sizeof(double) * cert.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, wait_stream(h->stream));
-    h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P, dni, dnd, W};
+    h->env.track = Track{d, d + P, d + 2 * P, d + 3 * P, P, dni, dnd, W, dring, dring + ring.size()};
     return MPOPIS_OK;
 }
 
@@ -372,7 +380,7 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     HIPCHK(h, hipMemcpyAsync(h->d_dscale0, ds.data(), sizeof(double) * cs, hipMemcpyHostToDevice, h->stream));
     // factor once: L0 (shared by all slots; the reference refactors the same Σ every call, :307)
     fill_i32(h->d_status, 0, h->B, h->stream);
-    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->potrf_coop());
+    launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->potrf_coop(), h->d_L0p, 0);
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, wait_stream(h->stream));
     if (h->h_status[0] != 0) { h->err = "PosDefException: Sigma is not positive definite"; return MPOPIS_ERR_NOT_PD; }
@@ -624,7 +632,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     auto mv = [db](auto*& p, ptrdiff_t stride) { if (p) p += db * stride; };
     mv(d_x, ss); mv(d_xext, kMaxCars * kCarExt); mv(d_t, 1); mv(d_done, 1);
     mv(d_U, cs); mv(d_Ucur, cs); mv(d_Uin, cs);
-    mv(d_Sig, nn); mv(d_L, nn); mv(d_tmpS, nn); mv(d_dscale, cs);
+    mv(d_Sig, nn); mv(d_L, nn); mv(d_tmpS, nn); mv(d_dscale, cs); mv(d_Lp, (ptrdiff_t)potrf_panel_doubles(cs));
     mv(d_Z, per); mv(d_E, per); mv(d_Zin, (ptrdiff_t)N * per); mv(d_cost, K); mv(d_w, K); mv(d_wsum, 1); mv(d_cmin, 1);
     mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
     mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_seeds, 1);
@@ -708,7 +716,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         else {
             time_begin(2);
             launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream,
-                         potrf_coop());
+                         potrf_coop(), d_Lp, potrf_panel_doubles(cs));
             time_end();
             Lp = d_L; Lstride = nn;
         }
@@ -733,10 +741,11 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             z_prefetched = false;
         } else if (!dsc && pol != MPOPIS_POL_MPPI) {
             // dense proposal: draw inside the unwhitening kernel when the shape allows it (no Z round trip through HBM)
-            fused = launch_sample_trmm_fused(Lp, Lstride, d_E, B, cs, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), d_active, stream);
-            if (!fused) launch_sample_normal(Zdst, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
+            fused = launch_sample_trmm_fused(Lp, Lstride, d_E, B, cs, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), d_active, stream, d_rng_tab,
+                                             Lstride ? d_Lp : d_L0p, Lstride ? potrf_panel_doubles(cs) : (size_t)0);
+            if (!fused) launch_sample_normal(Zdst, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream, d_rng_tab);
         } else {
-            launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream);
+            launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream, d_rng_tab);
         }
         if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
         time_end();
@@ -750,7 +759,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             fork_recorded = true;                                       // record on the main stream costs ~6 us of its critical path)
             (void)hipStreamWaitEvent(xstream[1], ev_fork, 0);
             // (no `active` predicate: the main stream's sort may clear active[b] concurrently; Z of a slot that stops is simply not consumed)
-            launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, nullptr, xstream[1]);
+            launch_sample_normal(d_Z, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)n, nullptr, nullptr, xstream[1], d_rng_tab);
             (void)hipEventRecord(ev_skew[1], xstream[1]);
             z_prefetched = true;
         }

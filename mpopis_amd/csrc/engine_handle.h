@@ -27,6 +27,7 @@ struct mpopis_handle {
     // proposal
     double *d_Sigma0 = nullptr, *d_L0 = nullptr, *d_dscale0 = nullptr;   // shared pol.Σ, its factor, sqrt(diag)
     double *d_Sig = nullptr, *d_L = nullptr, *d_tmpS = nullptr, *d_dscale = nullptr;
+    double *d_L0p = nullptr, *d_Lp = nullptr;     // the factors once more in the fused sampler's staging layout (potrf_panel_doubles(cs) per matrix; cs <= 128)
     bool sigma_diag = false;
     // samples / costs / weights
     double *d_Z = nullptr, *d_E = nullptr, *d_Zin = nullptr, *d_cost = nullptr, *d_w = nullptr;
@@ -36,6 +37,7 @@ struct mpopis_handle {
     double *d_wn = nullptr, *d_mu = nullptr, *d_gvec = nullptr, *d_control = nullptr, *d_reward = nullptr, *d_traj = nullptr;
     int *d_status = nullptr, *d_active = nullptr, *d_iters = nullptr;
     uint64_t* d_seeds = nullptr;
+    double* d_rng_tab = nullptr;            // Box-Muller tables (philox.h), filled at creation
     // elite selection / resampling
     int32_t *d_order = nullptr, *d_resi = nullptr, *d_alias = nullptr, *d_residx_log = nullptr, *d_resi_in = nullptr;
     double *d_resu = nullptr, *d_accept = nullptr, *d_resu_in = nullptr;

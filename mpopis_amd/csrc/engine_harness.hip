@@ -29,7 +29,7 @@ __global__ void k_harness_init(double* hs, int* alive, int B) {
 }
 
 // after env(act): cnt += 1; rew += reward(env); logging; violations; lap counter; termination
-struct StateNoise { double sx, sy, spsi; const uint64_t* seeds; };
+struct StateNoise { double sx, sy, spsi; const uint64_t* seeds; const double* rng_tab; };
 __global__ void k_harness_update(EnvDesc env, double* x, const int* done_env, const double* reward, const int* iters,
                                  double* hs, int* alive, const double* control, double* actlog, int step, int num_steps, int laps, int K, int B,
                                  StateNoise nz) {
@@ -38,8 +38,8 @@ __global__ void k_harness_update(EnvDesc env, double* x, const int* done_env, co
     double* h = hs + (size_t)b * kH_N;
     if (nz.seeds && env.kind == MPOPIS_ENV_CAR && env.ncars == 1) {            // :224-236 (sim_type == :cr only), after reward(env)
         double z0, z1, z2, z3;
-        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 0, &z0, &z1);
-        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 1, &z2, &z3);
+        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 0, nz.rng_tab, &z0, &z1);      // (tables read from global memory: a few lanes per step)
+        philox_normal_pair(nz.seeds[b], (uint32_t)step, 0x40000000u, 1, nz.rng_tab, &z2, &z3);
         double* s = x + (size_t)b * 8;
         s[0] += nz.sx * z0; s[1] += nz.sy * z1;
         const double dpsi = nz.spsi * z2;
@@ -123,7 +123,7 @@ int mpopis_handle::run_trials(int num_steps, int laps, double* records, double* 
         const bool noisy = noise_sx != 0.0 || noise_sy != 0.0 || noise_spsi != 0.0;
         hipLaunchKernelGGL(k_harness_update, dim3((B + 63) / 64), dim3(64), 0, stream, env, d_x, d_done, d_reward, d_iters, d_hs, d_alive,
                            d_control, d_actlog, s, num_steps, laps, K, B,
-                           StateNoise{noise_sx, noise_sy, noise_spsi, noisy ? d_seeds : (const uint64_t*)nullptr});
+                           StateNoise{noise_sx, noise_sy, noise_spsi, noisy ? d_seeds : (const uint64_t*)nullptr, d_rng_tab});
         // error status is sticky per call of policy_step_enqueue (it clears d_status): fold it into the host view now and then
         if ((s & 7) == 7 || s == num_steps) {
             (void)hipMemcpyAsync(h_alive.data(), d_alive, sizeof(int) * B, hipMemcpyDeviceToHost, stream);

@@ -27,8 +27,12 @@ namespace mpopis {
 // History at n = 100: per-pivot diagonal block + per-row substitution 63 us -> 4x4 sub-blocked block with explicit inverse 39 us
 // -> without the inverse (blocked MFMA substitution), one Newton step per pivot, branch-free row selection 29 us.
 // ---------------------------------------------------------------------------------------------
+// Lpanel (nullable): second copy of the factor in the layout the fused sampler stages through LDS (kernels_mfma.hip, k_trmm_LZ_mfma<true>):
+// [chunk = j / 16][p = (j & 3) 4 + ((j & 15) >> 2)][i < 128], zero above the diagonal and beyond n -- the sampler then copies whole rows
+// without address clamps or triangle predicates.
 __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
-                                                   int n, int npad, const double* scale, int* status, int* active) {
+                                                   int n, int npad, const double* scale, int* status, int* active,
+                                                   double* __restrict__ Lpanel, size_t pstride) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int failed;
@@ -122,6 +126,15 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
     }
     for (int j = wv; j < n; j += NW)
         for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
+    if (Lpanel) {
+        double* Lp = Lpanel + (size_t)b * pstride;
+        const int nch = (n + 15) / 16;
+        for (int e = tid; e < nch * 16 * kPanelRows; e += NTHR) {
+            const int i = e & (kPanelRows - 1), pr = (e / kPanelRows) & 15, c = e / (16 * kPanelRows);
+            const int j = c * 16 + (pr & 3) * 4 + (pr >> 2);                  // p = (jc & 3) 4 + (jc >> 2)  <=>  jc = 4 (p & 3) + (p >> 2)
+            Lp[e] = (i < n && j < n && i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
+        }
+    }
 }
 
 // Global-memory variant for matrices that do not fit in LDS (cs = 300: three cars), one workgroup of 16 waves: the working
@@ -459,14 +472,16 @@ int coop_test_drop() {
     return v;
 }
 
+size_t potrf_panel_doubles(int n) { return n <= kPanelRows ? (size_t)((n + 15) / 16) * 16 * kPanelRows : 0; }
+
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
-                  const CoopCtx& coop) {
+                  const CoopCtx& coop, double* panel, size_t pstride) {
     const int npad = (n + kNB - 1) / kNB * kNB, npan = npad / kNB;
     const size_t bytes = (size_t)npad * npad * sizeof(double);
     if (bytes <= 150 * 1024) {
         static std::atomic<unsigned long long> seen{0};
         ensure_dyn_lds((const void*)k_potrf_lds, 150 * 1024, seen);
-        hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active);
+        hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active, n <= kPanelRows ? panel : nullptr, pstride);
         return;
     }
     static const int env_G = [] { const char* e = getenv("MPOPIS_POTRF_G"); return e ? atoi(e) : -1; }();

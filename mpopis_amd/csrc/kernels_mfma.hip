@@ -28,15 +28,17 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 //              current chunk from the Philox streams (same counters as k_sample_normal_pair, i.e. the same numbers), two
 //              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
 //              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
-struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; };
+struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; const double* panel; size_t pstride; };
 // 4 waves per SIMD (128 VGPRs; the LDS panel allows 4 workgroups per CU): measured 5 % faster than the default 3 for the fused
 // sampler (Philox / Box-Muller VALU work of one wave fills the slots in which another waits on the matrix cores)
 template <bool RNG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
                                                       double* __restrict__ E, int n, int K, const int* active, RngArgs rng) {
     __shared__ double Ls[2][16][kTrmmLd];
+    __shared__ double sh_tab[RNG ? kRngTabDoubles : 1];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
+    if (RNG) { stage_rng_tab(sh_tab, rng.tab, threadIdx.x, 256); __syncthreads(); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wv) * 16;
     const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
@@ -67,10 +69,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int rho = 0; rho < 2; ++rho) {
             const int row = j0 + 4 * lk + 2 * rho;
             const uint64_t lin = (uint64_t)kk * n + min(row, n - 2);
-            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, &bz[2 * rho], &bz[2 * rho + 1]);
+            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, sh_tab, &bz[2 * rho], &bz[2 * rho + 1]);
         }
     };
+    // RNG: L comes as the pre-arranged, zero-filled panel copy the Cholesky kernel wrote (k_potrf_lds, Lpanel): row p of chunk c is LDS row p,
+    // so staging is 8 plain loads + 8 plain LDS stores per thread and chunk (the generic path spends ~10 VALU per element on clamps,
+    // address arithmetic and the triangle predicate -- on the datapath the Philox / Box-Muller work and the MFMAs share)
+    const double* Pb = RNG ? rng.panel + (size_t)b * rng.pstride + (size_t)(sj * 8) * kPanelRows + si : nullptr;
     auto load_chunk = [&](int j0) {
+        if (RNG) {
+            const double* pc = Pb + (size_t)j0 * kPanelRows;       // chunk j0 / 16: 16 rows of kPanelRows
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lreg[u] = pc[(size_t)u * kPanelRows];
+            draw_chunk(j0);
+            return;
+        }
 #pragma unroll
         // unconditional loads from clamped addresses (a predicated load costs an exec-masked block + vmcnt(0) each);
         // out-of-range / upper-triangle entries are zeroed when the chunk is written to LDS / used
@@ -84,10 +97,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     load_chunk(0);
     int buf = 0;
     for (int j0 = 0; j0 < jend; j0 += 16, buf ^= 1) {
+        if (RNG) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int jc = sj + 2 * u, j = j0 + jc;
-            Ls[buf][(jc & 3) * 4 + (jc >> 2)][si] = (gi < n && j < n && j <= gi) ? lreg[u] : 0.0;
+            for (int u = 0; u < 8; ++u) Ls[buf][sj * 8 + u][si] = lreg[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jc = sj + 2 * u, j = j0 + jc;
+                Ls[buf][(jc & 3) * 4 + (jc >> 2)][si] = (gi < n && j < n && j <= gi) ? lreg[u] : 0.0;
+            }
         }
         double bc[4];
 #pragma unroll
@@ -121,15 +139,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
     const int nt = (n + 15) / 16;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       RngArgs{nullptr, 0, 0});
+                       RngArgs{nullptr, 0, 0, nullptr, nullptr, 0});
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
 bool sample_trmm_fusable(int n) { return !(n & 1) && (n + 15) / 16 <= kTrmmTiles; }
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                              const int* active, hipStream_t s) {
-    if (!sample_trmm_fusable(n)) return false;
+                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride) {
+    if (!sample_trmm_fusable(n) || !panel) return false;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       RngArgs{seeds, slo, shi});
+                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride});
     return true;
 }
 // ---------------------------------------------------------------------------------------------

@@ -50,8 +50,11 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
         sh_trk[3 * P + i] = a.env.track.n2[i];
     }
     for (int i = threadIdx.x; i < NS; i += 64 * NC * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
+    double* sh_ring = reinterpret_cast<double*>(sh_ni + NS + (NS & 1));   // ring table [(P+4)][4] + certification radii [P] (car_dynamics.h: Track::ring)
+    for (int i = threadIdx.x; i < 4 * (P + 4); i += 64 * NC * SPB) sh_ring[i] = a.env.track.ring[i];
+    for (int i = threadIdx.x; i < P; i += 64 * NC * SPB) sh_ring[4 * (P + 4) + i] = a.env.track.ring_cert[i];
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W};
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_ring + 4 * (P + 4)};
     CarState s;                                               // wave-uniform start state (+ sin/cos), scalar loads
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
@@ -132,12 +135,15 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
         sh_trk[3 * P + i] = a.env.track.n2[i];
     }
     for (int i = threadIdx.x; i < NS; i += 64 * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
+    double* sh_ring = reinterpret_cast<double*>(sh_ni + NS + (NS & 1));   // ring table [(P+4)][4] + certification radii [P]
+    for (int i = threadIdx.x; i < 4 * (P + 4); i += 64 * SPB) sh_ring[i] = a.env.track.ring[i];
+    for (int i = threadIdx.x; i < P; i += 64 * SPB) sh_ring[4 * (P + 4) + i] = a.env.track.ring_cert[i];
     if (threadIdx.x < NC) {
         const int q = threadIdx.x;
         sh_bnd[q][0] = a.env.lo[2 * q]; sh_bnd[q][1] = a.env.hi[2 * q]; sh_bnd[q][2] = a.env.lo[2 * q + 1]; sh_bnd[q][3] = a.env.hi[2 * q + 1];
     }
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W};
+    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_ring + 4 * (P + 4)};
     CarState s;
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
@@ -277,7 +283,8 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
         return;
     }
     const int P = a.env.track.P, W = a.env.track.nbrw;
-    const size_t lds = (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int));
+    const size_t lds = (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int)) + 8 /* alignment of the ring table */ +
+                       (size_t)(4 * (P + 4) + P) * sizeof(double);
     // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 waves share the LDS tables
     const bool wide = a.K >= 1024;
     const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B);

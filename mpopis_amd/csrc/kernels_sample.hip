@@ -10,15 +10,30 @@
 
 namespace mpopis {
 
+__global__ void k_rng_tab_init(double* g_rng_tab) {
+    const int i = threadIdx.x;
+    if (i < kRngTabLog) {
+        const double c = (i == kRngTabLog - 1) ? 1.0 : 0.5 * (1.0 + (i + 0.5) / kRngTabLog);
+        g_rng_tab[2 * i] = 1.0 / c; g_rng_tab[2 * i + 1] = log(c);
+    } else if (i < kRngTabLog + kRngTabSc) {
+        const int j = i - kRngTabLog;
+        g_rng_tab[2 * i] = sinpi((2.0 * j + 1.0) / kRngTabSc); g_rng_tab[2 * i + 1] = cospi((2.0 * j + 1.0) / kRngTabSc);
+    }
+}
+void launch_rng_tab_init(double* gtab, hipStream_t s) { hipLaunchKernelGGL(k_rng_tab_init, dim3(1), dim3(256), 0, s, gtab); }
+
 // Z[b][r][k] (K fastest) = standard normal number `lin` of the reference's draw order, scaled by
 // dscale[r] when the Cholesky factor is diagonal (then Z is already E).
 //   G-variants: lin = k*cs + r            (randn! fills the cs x K matrix column-major)
 //   :mppi     : lin = (t*K + k)*as + a    with r = t*as + a  (k fastest, then t)
 __global__ void __launch_bounds__(256) k_sample_normal(double* __restrict__ Z, int cs, int K, int as, int mppi_order,
                                                        const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                                                       const double* dscale, const int* active) {
+                                                       const double* dscale, const int* active, const double* __restrict__ rng_tab) {
     const int b = blockIdx.z;
     if (active && !active[b]) return;
+    __shared__ double sh_tab[kRngTabDoubles];
+    stage_rng_tab(sh_tab, rng_tab, threadIdx.x, 256);
+    __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int r = blockIdx.y;
     if (k >= K) return;
@@ -26,7 +41,7 @@ __global__ void __launch_bounds__(256) k_sample_normal(double* __restrict__ Z, i
     if (mppi_order) { const int t = r / as, a = r - t * as; lin = ((uint64_t)t * K + k) * as + a; }
     else lin = (uint64_t)k * cs + r;
     double z0, z1;
-    philox_normal_pair(seeds[b], slo, shi, lin >> 1, &z0, &z1);
+    philox_normal_pair(seeds[b], slo, shi, lin >> 1, sh_tab, &z0, &z1);
     double z = (lin & 1) ? z1 : z0;
     if (dscale) z *= dscale[(size_t)b * cs + r];
     Z[((size_t)b * cs + r) * K + k] = z;
@@ -36,9 +51,12 @@ __global__ void __launch_bounds__(256) k_sample_normal(double* __restrict__ Z, i
 // (linear indices 2p, 2p+1) to sit in adjacent rows of the same sample: cs even (G order) / as even (:mppi).
 __global__ void __launch_bounds__(256) k_sample_normal_pair(double* __restrict__ Z, int cs, int K, int as, int mppi_order,
                                                             const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                                                            const double* dscale, const int* active) {
+                                                            const double* dscale, const int* active, const double* __restrict__ rng_tab) {
     const int b = blockIdx.z;
     if (active && !active[b]) return;
+    __shared__ double sh_tab[kRngTabDoubles];
+    stage_rng_tab(sh_tab, rng_tab, threadIdx.x, 256);
+    __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int r = 2 * blockIdx.y;                               // rows r, r+1
     if (k >= K) return;
@@ -46,19 +64,19 @@ __global__ void __launch_bounds__(256) k_sample_normal_pair(double* __restrict__
     if (mppi_order) { const int t = r / as, a = r - t * as; lin = ((uint64_t)t * K + k) * as + a; }
     else lin = (uint64_t)k * cs + r;
     double z0, z1;
-    philox_normal_pair(seeds[b], slo, shi, lin >> 1, &z0, &z1);
+    philox_normal_pair(seeds[b], slo, shi, lin >> 1, sh_tab, &z0, &z1);
     if (dscale) { z0 *= dscale[(size_t)b * cs + r]; z1 *= dscale[(size_t)b * cs + r + 1]; }
     Z[((size_t)b * cs + r) * K + k] = z0;
     Z[((size_t)b * cs + r + 1) * K + k] = z1;
 }
 
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
-                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s) {
+                          uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s, const double* rng_tab) {
     const bool pairable = mppi_order ? (as % 2 == 0) : (cs % 2 == 0);
     if (pairable)
-        hipLaunchKernelGGL(k_sample_normal_pair, dim3((K + 255) / 256, cs / 2, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
+        hipLaunchKernelGGL(k_sample_normal_pair, dim3((K + 255) / 256, cs / 2, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active, rng_tab);
     else
-        hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active);
+        hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active, rng_tab);
 }
 
 // resampling draws for :pmcmppi (rand(rng, Categorical(ws), K), :805): i uniform in [0,K), u in [0,1)

@@ -5,12 +5,13 @@
 #include <vector>
 using namespace mpopis;
 #include <algorithm>
-static std::vector<double> g_nd; static std::vector<int> g_ni;
+static std::vector<double> g_nd, g_ring, g_cert; static std::vector<int> g_ni;
 static Track mk(int P, const double* tx, const double* ty, const double* tw, std::vector<double>& n2) {
     n2.resize(P); for (int i = 0; i < P; ++i) n2[i] = tx[i] * tx[i] + ty[i] * ty[i];
     const int W = std::min<int>(kTrackNbrW, P);
     build_track_tables(P, tx, ty, g_nd, g_ni);
-    return Track{tx, ty, tw, n2.data(), P, g_ni.data(), g_nd.data(), W};
+    build_track_ring(P, tx, ty, tw, g_nd, g_ring, g_cert);
+    return Track{tx, ty, tw, n2.data(), P, g_ni.data(), g_nd.data(), W, g_ring.data(), g_cert.data()};
 }
 extern "C" {
 void shim_car_action_step(const double* p20, double* s8, double a0, double a1) {
@@ -41,5 +42,20 @@ double shim_mc_reward(const double* p8, const double* s2, int done) { McParams p
 extern "C" int shim_within_anchor(int P, const double* tx, const double* ty, const double* tw, double px, double py, int* anchor, double* dist) {
     static std::vector<double> n2; static Track tk; static const double* last = nullptr;
     if (last != tx) { tk = mk(P, tx, ty, tw, n2); last = tx; }
+    return within_track(tk, px, py, dist, anchor) ? 1 : 0;
+}
+// the rollout kernels' path: ring fast path when it applies, general search otherwise (car_dynamics.h: car_reward); *fast = which one ran
+extern "C" int shim_within_ring(int P, const double* tx, const double* ty, const double* tw, double px, double py, int* anchor, double* dist, int* fast) {
+    static std::vector<double> n2; static Track tk; static const double* last = nullptr;
+    if (last != tx) { tk = mk(P, tx, ty, tw, n2); last = tx; }
+    int rel = 0;
+    const bool ok = ring_candidates(tk.ring, tk.ring_cert, *anchor, px, py, &rel);
+    *fast = ok ? 1 : 0;
+    if (ok) {
+        const bool w = ring_project(tk.ring, *anchor, rel, px, py, dist);
+        const int mi = *anchor + rel;
+        *anchor = (mi < 0) ? tk.P - 1 : ((mi >= tk.P) ? 0 : mi);
+        return w ? 1 : 0;
+    }
     return within_track(tk, px, py, dist, anchor) ? 1 : 0;
 }

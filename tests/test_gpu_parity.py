@@ -214,6 +214,32 @@ def test_device_rng_matches_oracle_philox(eng_mod, oracle, track):
     eng.close()
 
 
+def test_device_rng_normals_full_size(eng_mod, oracle, track):
+    """400 k normals per slot through the table-based Box-Muller (philox.h): every one within 1e-13 of the oracle's libm evaluation, tails
+    included, and the fused in-kernel sampler (dense Σ) gives L times the same numbers."""
+    K, T = 4096, 50
+    cs = 2 * T
+    eng = eng_mod.Engine("car", 1, "gmppi", K, T, batch=2, lam=10.0, cov=[0.0625, 0.1], track=track, seed=99)
+    got = eng.policy_step(None, want_E=True)
+    zmax = 0.0
+    for b in range(2):
+        z = oracle.philox_normals(99 + b + 1, 0, 0, cs * K).reshape(K, cs)
+        zmax = max(zmax, float(np.abs(z).max()))
+        assert np.max(np.abs(got["E"][b] - z * np.sqrt(np.tile([0.0625, 0.1], T)))) < 1e-13
+    assert zmax > 4.5                                                   # the sample reaches into the tails
+    eng.close()
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((cs, cs)) * 0.05
+    Sig = A @ A.T + np.diag(np.tile([0.0625, 0.1], T))
+    eng = eng_mod.Engine("car", 1, "gmppi", K, T, batch=2, lam=10.0, cov=Sig, track=track, seed=99)
+    got = eng.policy_step(None, want_E=True)
+    Lc = np.linalg.cholesky(Sig)
+    for b in range(2):
+        z = oracle.philox_normals(99 + b + 1, 0, 0, cs * K).reshape(K, cs)
+        assert np.max(np.abs(got["E"][b] - z @ Lc.T)) < 1e-12
+    eng.close()
+
+
 def test_env_step_and_errors(eng_mod, oracle, track):
     from mpopis_amd._lib import MPOPISError
     eng = eng_mod.Engine("car", 3, "gmppi", 64, 5, batch=2, lam=10.0, cov=np.tile([0.0625, 0.1], 3), track=track)

@@ -59,3 +59,38 @@ def test_anchored_search_matches_findmin(shim, oracle, name, track):
         assert bool(w) == rw and abs(dist.value - rd) <= 1e-9 * max(1.0, rd), (name, q, pos, dist.value, rd)
         d2 = (tx - pos[0]) ** 2 + (ty - pos[1]) ** 2              # the anchor left behind is the first minimum (up to exact-tie rounding)
         assert d2[anchor.value] <= d2.min() * (1 + 1e-12) + 1e-12
+
+
+@pytest.mark.parametrize("name,track", _tracks(), ids=[n for n, _ in _tracks()])
+def test_ring_fast_path_matches_findmin_and_general_search(shim, oracle, name, track):
+    """The rollout kernels' straight-line path (ring table, certified candidates, no ties) against the oracle's literal findmin AND bit for bit
+    against the general anchored search from the same anchor: a rollout's cost must not depend on which of the two a wave took."""
+    tx, ty, tw = (np.ascontiguousarray(a, dtype=np.float64) for a in track)
+    L = shim
+    L.shim_within_ring.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, C.POINTER(C.c_int), dp, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(abs(hash(name)) % 2 ** 31 + 1)
+    P = len(tx)
+    anchor = C.c_int(-1)
+    k = int(rng.integers(0, P))
+    pos = np.array([tx[k], ty[k]]) + rng.normal(0, 3, 2)
+    nfast = 0
+    nq = 1500
+    for q in range(nq):
+        if q % 97 == 0:
+            k = int(rng.integers(0, P)); pos = np.array([tx[k], ty[k]]) + rng.normal(0, 12, 2)
+            if q % 2: anchor = C.c_int(-1)
+        else:
+            pos = pos + rng.normal(0, 2.0, 2)
+            if q % 13 == 0: pos = pos + rng.normal(0, 10, 2)
+        a_gen, a_ring = C.c_int(anchor.value), C.c_int(anchor.value)
+        d_gen, d_ring, fast = C.c_double(), C.c_double(), C.c_int()
+        args = (P, tx.ctypes.data_as(dp), ty.ctypes.data_as(dp), tw.ctypes.data_as(dp), float(pos[0]), float(pos[1]))
+        w_gen = L.shim_within_anchor(*args, C.byref(a_gen), C.byref(d_gen))
+        w_ring = L.shim_within_ring(*args, C.byref(a_ring), C.byref(d_ring), C.byref(fast))
+        nfast += fast.value
+        assert w_ring == w_gen and a_ring.value == a_gen.value and d_ring.value == d_gen.value, (name, q, pos, fast.value)   # bit-identical
+        rw, rd = oracle.within_track((tx, ty, tw), pos)
+        assert bool(w_ring) == rw and abs(d_ring.value - rd) <= 1e-9 * max(1.0, rd)
+        anchor = a_ring
+    if P >= 8 and name != "hairpin":
+        assert nfast > nq // 3, (name, nfast)                    # the fast path is common even on this random walk with excursions
