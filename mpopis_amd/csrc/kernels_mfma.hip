@@ -219,14 +219,16 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
         // so the separate reweighting launch between rollout and moments disappears.  Done before the main loop, while the staging registers
         // are still free.
         const double rho = cost_unkey(cminp[b]);
-        for (int kq = kbeg + (int)threadIdx.x; kq < kend; kq += 256) wsl[kq - kbeg] = exp(neg_inv_lambda * (costp[(size_t)b * K + kq] - rho));
+        // (stored as sqrt(w_k) = exp(-1/(2λ) (c_k - ρ)): the rows are staged as sqrt(w_k) x_k, see below)
+        for (int kq = kbeg + (int)threadIdx.x; kq < kend; kq += 256) wsl[kq - kbeg] = exp(0.5 * neg_inv_lambda * (costp[(size_t)b * K + kq] - rho));
         __syncthreads();
     }
     bool kin_cur = false;
+    const bool weighted = costp || wb;                          // uniform
     auto load_chunk = [&](int c0) {                             // unconditional loads from clamped addresses
         const int kq = min(c0 + skk, kend - 1);
         const int col = ib ? ib[kq] : kq;
-        wreg = costp ? wsl[kq - kbeg] : (wb ? wb[col] : 1.0);
+        wreg = costp ? wsl[kq - kbeg] : (wb ? sqrt(wb[col]) : 1.0);      // sqrt(w_k)
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) xreg[u] = Xb[(size_t)min(sr0 + u * kRowStep, cs - 1) * K + col];
     };
@@ -237,24 +239,26 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     if (kbeg < kend) load_chunk(kbeg);
     for (int c0 = kbeg; c0 < kend; c0 += KC) {
         kin_cur = (c0 + skk) < kend;
+        // Rows are staged as sqrt(w_k) x_k: Σ_k w_k x_a x_b = Σ_k (sqrt(w_k) x_a)(sqrt(w_k) x_b), so the weight costs one multiply per staged
+        // element (28 per thread and chunk) instead of one per MFMA operand (112 per lane and chunk, on the datapath the MFMAs share).
+        const double sw = weighted ? wreg : 1.0;
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) {
             const int row = sr0 + u * kRowStep;
             double v = xreg[u];
             if (SQ) { v = (v - mureg[u]) * rsreg[u]; v *= v; }
-            // zero padded; aug: the first padding row carries ones, so row cs of the scatter is Σ_k w_k x_k (the weighted
-            // mean comes out of the same pass over X and the separate E·w kernel is not needed)
-            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : ((aug && row == cs && kin_cur) ? 1.0 : 0.0);
+            if (weighted) v *= sw;
+            // zero padded; aug: the first padding row carries ones (times sqrt(w_k)), so row cs of the scatter is Σ_k w_k x_k (the weighted
+            // mean comes out of the same pass over X and the separate E·w kernel is not needed) and its diagonal entry is Σ_k w_k
+            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : ((aug && row == cs && kin_cur) ? sw : 0.0);
         }
-        if (sr0 == 0) ws[skk] = kin_cur ? wreg : 0.0;
         __syncthreads();
         if (c0 + KC < kend) load_chunk(c0 + KC);                // next chunk's loads fly during the MFMAs
 #pragma unroll
         for (int kk0 = 0; kk0 < KC; kk0 += 4) {
-            const double wk = ws[kk0 + lk];
 #pragma unroll
-            for (int p = 0; p < kPairsPerWave; ++p)             // (x_a - μ_a) w_k  x  (x_b - μ_b)
-                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[p][kk0] * wk, pB[p][kk0], acc[p], 0, 0, 0);
+            for (int p = 0; p < kPairsPerWave; ++p)             // sqrt(w_k) x_a  x  sqrt(w_k) x_b
+                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[p][kk0], pB[p][kk0], acc[p], 0, 0, 0);
         }
         __syncthreads();
     }
