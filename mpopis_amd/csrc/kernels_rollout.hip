@@ -21,7 +21,31 @@ namespace mpopis {
 
 // One car (NC = 1, CarRacingEnv): SPB sample-waves per workgroup share one LDS copy of the track tables
 // LOG: the trajectory logger is on (a.traj != nullptr) -- only then is the heading angle psi itself tracked
-template <int NC, int SPB, bool LOG>
+// Track tables into LDS (dynamic LDS layout: ring table [(P+4)][4] + certification radii [P]; with ALL: + x, y, w, |q|^2 [4][P] + neighbour
+// distances [P][W+1] + neighbour indices [P][W+1]).  Returns the Track the rollout uses; the caller synchronises.
+template <bool ALL>
+__device__ __forceinline__ Track stage_track(const Track& g, double* sh, int tid, int nthreads) {
+    const int P = g.P, W = g.nbrw, NS = P * (W + 1);
+    double* sh_ring = sh;
+    double* sh_cert = sh + 4 * (P + 4);
+    for (int i = tid; i < 4 * (P + 4); i += nthreads) sh_ring[i] = g.ring[i];
+    for (int i = tid; i < P; i += nthreads) sh_cert[i] = g.ring_cert[i];
+    if (!ALL) return Track{g.x, g.y, g.w, g.n2, P, g.nbr_idx, g.nbr_dist, W, sh_ring, sh_cert};
+    double* sh_trk = sh_cert + P;
+    double* sh_nd = sh_trk + 4 * P;
+    int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);
+    for (int i = tid; i < P; i += nthreads) { sh_trk[i] = g.x[i]; sh_trk[P + i] = g.y[i]; sh_trk[2 * P + i] = g.w[i]; sh_trk[3 * P + i] = g.n2[i]; }
+    for (int i = tid; i < NS; i += nthreads) { sh_nd[i] = g.nbr_dist[i]; sh_ni[i] = g.nbr_idx[i]; }
+    return Track{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_cert};
+}
+inline size_t track_lds_bytes(int P, int W, bool all) {
+    return (size_t)(4 * (P + 4) + P) * sizeof(double) + (all ? (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int)) : 0);
+}
+
+// TLDS: every track table fits the default 64 KB of dynamic LDS (P <= ~230 points: all bundled tracks).  Otherwise only the ring table of the
+// straight-line nearest-point search is staged (40 B per point) and the general search -- first step of a rollout, lanes far off their
+// anchor -- reads the coordinate / neighbour tables from global memory.
+template <int NC, int SPB, bool LOG, bool TLDS>
 __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car(RolloutArgs a) {
     static_assert(NC == 1, "multi-car envs run k_rollout_cars");
     const int b = blockIdx.y;
@@ -40,21 +64,9 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
 
     const CarParams& p = a.env.car;
     // stage the (wave-uniform, read-only) track in LDS: uniform-address ds_reads broadcast to all lanes
-    extern __shared__ __attribute__((aligned(16))) double sh_trk[];
-    const int P = a.env.track.P;
-    const int W = a.env.track.nbrw, NS = P * (W + 1);
-    double* sh_nd = sh_trk + 4 * P;                           // neighbour distances [P][W+1]
-    int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);          // neighbour indices   [P][W+1]
-    for (int i = threadIdx.x; i < P; i += 64 * NC * SPB) {
-        sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
-        sh_trk[3 * P + i] = a.env.track.n2[i];
-    }
-    for (int i = threadIdx.x; i < NS; i += 64 * NC * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
-    double* sh_ring = reinterpret_cast<double*>(sh_ni + NS + (NS & 1));   // ring table [(P+4)][4] + certification radii [P] (car_dynamics.h: Track::ring)
-    for (int i = threadIdx.x; i < 4 * (P + 4); i += 64 * NC * SPB) sh_ring[i] = a.env.track.ring[i];
-    for (int i = threadIdx.x; i < P; i += 64 * NC * SPB) sh_ring[4 * (P + 4) + i] = a.env.track.ring_cert[i];
+    extern __shared__ __attribute__((aligned(16))) double sh_dyn[];
+    const Track tk = stage_track<TLDS>(a.env.track, sh_dyn, threadIdx.x, 64 * NC * SPB);
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_ring + 4 * (P + 4)};
     CarState s;                                               // wave-uniform start state (+ sin/cos), scalar loads
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
@@ -106,7 +118,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
 // Per-lane (not wave-uniform) here: the start state, the nominal control U (vector loads, one step ahead like E) and the action bounds
 // (LDS table).  The pairwise reward terms (multi-car_racing.jl:145-158) read the other cars' (x, y) by lane shuffles; the sample's cost is
 // the sum over its cars in car order, gathered the same way.  SPB waves per workgroup share one LDS copy of the track tables.
-template <int NC, int SPB, bool LOG, int WPE>
+template <int NC, int SPB, bool LOG, int WPE, bool TLDS>
 __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_rollout_cars(RolloutArgs a) {
     static_assert(NC >= 2 && NC <= kMaxCars, "2..4 cars");
     constexpr int S = 64 / NC;                                // samples per wave
@@ -124,26 +136,14 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
     (void)ss;
 
     const CarParams& p = a.env.car;
-    extern __shared__ __attribute__((aligned(16))) double sh_trk[];
-    const int P = a.env.track.P;
-    const int W = a.env.track.nbrw, NS = P * (W + 1);
-    double* sh_nd = sh_trk + 4 * P;                           // neighbour distances [P][W+1]
-    int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);          // neighbour indices   [P][W+1]
+    extern __shared__ __attribute__((aligned(16))) double sh_dyn[];
     __shared__ double sh_bnd[NC][4];                          // lo0, hi0, lo1, hi1 per car
-    for (int i = threadIdx.x; i < P; i += 64 * SPB) {
-        sh_trk[i] = a.env.track.x[i]; sh_trk[P + i] = a.env.track.y[i]; sh_trk[2 * P + i] = a.env.track.w[i];
-        sh_trk[3 * P + i] = a.env.track.n2[i];
-    }
-    for (int i = threadIdx.x; i < NS; i += 64 * SPB) { sh_nd[i] = a.env.track.nbr_dist[i]; sh_ni[i] = a.env.track.nbr_idx[i]; }
-    double* sh_ring = reinterpret_cast<double*>(sh_ni + NS + (NS & 1));   // ring table [(P+4)][4] + certification radii [P]
-    for (int i = threadIdx.x; i < 4 * (P + 4); i += 64 * SPB) sh_ring[i] = a.env.track.ring[i];
-    for (int i = threadIdx.x; i < P; i += 64 * SPB) sh_ring[4 * (P + 4) + i] = a.env.track.ring_cert[i];
+    const Track tk = stage_track<TLDS>(a.env.track, sh_dyn, threadIdx.x, 64 * SPB);
     if (threadIdx.x < NC) {
         const int q = threadIdx.x;
         sh_bnd[q][0] = a.env.lo[2 * q]; sh_bnd[q][1] = a.env.hi[2 * q]; sh_bnd[q][2] = a.env.lo[2 * q + 1]; sh_bnd[q][3] = a.env.hi[2 * q + 1];
     }
     __syncthreads();
-    const Track tk{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_ring + 4 * (P + 4)};
     CarState s;
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
@@ -273,6 +273,14 @@ void launch_step_begin(int* status, int* active, const int* alive, int* iters, c
     hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin);
 }
 
+// one `seen` mask per kernel (non-type template parameter): large tracks need the dynamic-LDS limit raised, per device
+template <void (*KERNEL)(RolloutArgs)>
+static void launch_rollout_kernel(dim3 grid, int block, size_t lds, hipStream_t st, const RolloutArgs& a) {
+    static std::atomic<unsigned long long> seen{0};
+    if (lds > 60 * 1024) ensure_dyn_lds((const void*)KERNEL, 96 * 1024, seen);
+    hipLaunchKernelGGL(KERNEL, grid, dim3(block), lds, st, a);
+}
+
 void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     if (a.env.kind == MPOPIS_ENV_MOUNTAINCAR) {
         hipLaunchKernelGGL(k_rollout_simple<2>, dim3((a.K + 63) / 64, a.B), dim3(64), 0, st, a);
@@ -283,27 +291,31 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
         return;
     }
     const int P = a.env.track.P, W = a.env.track.nbrw;
-    const size_t lds = (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int)) + 8 /* alignment of the ring table */ +
-                       (size_t)(4 * (P + 4) + P) * sizeof(double);
+    // every table in LDS when that fits the default 64 KB (all bundled tracks: 48-60 points); larger tracks (Track(infile; sample_factor = 1):
+    // ~1000 points) stage the ring table only (<= 82 KB at the 2048-point limit: the kernels' dynamic-LDS limit is raised to 96 KB once)
+    const bool tl = track_lds_bytes(P, W, true) <= 60 * 1024;
+    const size_t lds = track_lds_bytes(P, W, tl);
     // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 waves share the LDS tables
     const bool wide = a.K >= 1024;
     const dim3 g1((a.K + 63) / 64, a.B), g4((a.K + 255) / 256, a.B);
+#define MPOPIS_LAUNCH_K(KERNEL, GRID, BLOCK) launch_rollout_kernel<KERNEL>(GRID, BLOCK, lds, st, a)
 #define MPOPIS_LAUNCH_CAR(NC, SPB, GRID, BLOCK)                                                        \
     do {                                                                                               \
-        if (a.traj) hipLaunchKernelGGL((k_rollout_car<NC, SPB, true>), GRID, dim3(BLOCK), lds, st, a);  \
-        else        hipLaunchKernelGGL((k_rollout_car<NC, SPB, false>), GRID, dim3(BLOCK), lds, st, a); \
+        if (a.traj) { if (tl) MPOPIS_LAUNCH_K((k_rollout_car<NC, SPB, true, true>), GRID, BLOCK); else MPOPIS_LAUNCH_K((k_rollout_car<NC, SPB, true, false>), GRID, BLOCK); }   \
+        else        { if (tl) MPOPIS_LAUNCH_K((k_rollout_car<NC, SPB, false, true>), GRID, BLOCK); else MPOPIS_LAUNCH_K((k_rollout_car<NC, SPB, false, false>), GRID, BLOCK); } \
     } while (0)
-#define MPOPIS_LAUNCH_CARS_W(NC, WPE)                                                                                 \
-    do {                                                                                                              \
-        const int S_ = 64 / NC;                                                                                       \
-        const dim3 gw((a.K + 4 * S_ - 1) / (4 * S_), a.B), gn((a.K + S_ - 1) / S_, a.B);                               \
-        if (wide) { if (a.traj) hipLaunchKernelGGL((k_rollout_cars<NC, 4, true, WPE>), gw, dim3(256), lds, st, a);    \
-                    else        hipLaunchKernelGGL((k_rollout_cars<NC, 4, false, WPE>), gw, dim3(256), lds, st, a); } \
-        else      { if (a.traj) hipLaunchKernelGGL((k_rollout_cars<NC, 1, true, WPE>), gn, dim3(64), lds, st, a);     \
-                    else        hipLaunchKernelGGL((k_rollout_cars<NC, 1, false, WPE>), gn, dim3(64), lds, st, a); }  \
+#define MPOPIS_LAUNCH_CARS_W(NC, WPE, SPB, GRID, BLOCK)                                                                                                      \
+    do {                                                                                                                                                    \
+        if (a.traj) { if (tl) MPOPIS_LAUNCH_K((k_rollout_cars<NC, SPB, true, WPE, true>), GRID, BLOCK); else MPOPIS_LAUNCH_K((k_rollout_cars<NC, SPB, true, WPE, false>), GRID, BLOCK); }   \
+        else        { if (tl) MPOPIS_LAUNCH_K((k_rollout_cars<NC, SPB, false, WPE, true>), GRID, BLOCK); else MPOPIS_LAUNCH_K((k_rollout_cars<NC, SPB, false, WPE, false>), GRID, BLOCK); } \
     } while (0)
-    static const int env_wpe = [] { const char* e = getenv("MPOPIS_CARS_WPE"); return e ? atoi(e) : 3; }();      // waves per SIMD of the multi-car kernel: 3 (168 VGPRs, no spills; 1411 us at 64 three-car trials) beats 4 (128 VGPRs, 33 spills: 1509 us)
-#define MPOPIS_LAUNCH_CARS(NC) do { if (env_wpe == 3) MPOPIS_LAUNCH_CARS_W(NC, 3); else MPOPIS_LAUNCH_CARS_W(NC, 4); } while (0)
+    // waves per SIMD of the multi-car kernel: 3 (168 VGPRs, no spills; 1411 us at 64 three-car trials) beats 4 (128 VGPRs, 33 spills: 1509 us)
+#define MPOPIS_LAUNCH_CARS(NC)                                                                                   \
+    do {                                                                                                         \
+        const int S_ = 64 / NC;                                                                                  \
+        const dim3 gw((a.K + 4 * S_ - 1) / (4 * S_), a.B), gn((a.K + S_ - 1) / S_, a.B);                          \
+        if (wide) MPOPIS_LAUNCH_CARS_W(NC, 3, 4, gw, 256); else MPOPIS_LAUNCH_CARS_W(NC, 3, 1, gn, 64);           \
+    } while (0)
     switch (a.env.ncars) {
         case 1: if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64); break;
         case 2: MPOPIS_LAUNCH_CARS(2); break;
@@ -313,6 +325,7 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     }
 #undef MPOPIS_LAUNCH_CARS
 #undef MPOPIS_LAUNCH_CARS_W
+#undef MPOPIS_LAUNCH_K
 #undef MPOPIS_LAUNCH_CAR
 }
 

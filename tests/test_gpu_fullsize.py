@@ -93,3 +93,30 @@ def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
     assert np.array_equal(g["res_idx0"][0, 0], r["res_idx0"][0])
     assert len(ref) == K
     eng.close()
+
+
+@pytest.mark.parametrize("P,ncars", [(300, 1), (960, 1), (2048, 1), (960, 3)])
+def test_large_tracks_rollout_costs(eng_mod, oracle, P, ncars):
+    """Track(infile; sample_factor = 1) has ~960 points (car_racing_tracks.jl:16-23; the default factor 20 gives 48): beyond ~230 points the
+    track tables no longer fit the rollout kernels' default LDS budget -- only the ring table of the straight-line nearest-point search is
+    staged and the general search reads global memory.  Costs against the oracle on a dense oval, some samples far off the track."""
+    a = np.linspace(0, 2 * np.pi, P, endpoint=False)
+    trk = (np.ascontiguousarray(120 * np.cos(a) - 120), np.ascontiguousarray(60 * np.sin(a)), np.full(P, 15.0))
+    K, T, B = 512, 30, 2
+    cs = 2 * ncars * T
+    rng = np.random.default_rng(P + ncars)
+    env = oracle.OracleEnv("car", ncars, track=trk)
+    pol = oracle.OraclePolicy("gmppi", env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=np.tile([0.0625, 0.1], ncars), nthreads=8)
+    eng = eng_mod.Engine("car", ncars, "gmppi", K, T, batch=B, lam=10.0, cov=np.tile([0.0625, 0.1], ncars), track=trk)
+    U = rng.uniform(-0.3, 0.3, (B, cs))
+    U[:, 1::2] += 0.4
+    E = rng.standard_normal((B, K, cs)) * np.tile([0.25, 0.32], ncars * T)
+    E[0, :8] *= 8.0
+    x0 = np.stack([env.state for _ in range(B)])
+    x0[1, 3] = 25.0
+    got = eng.rollout_costs(U, E, x0=x0)
+    for b in range(B):
+        env.state = x0[b]
+        ref = pol.simulate_model(U[b], E[b].T)
+        assert np.max(np.abs(got[b] - ref) / (np.abs(ref) + 1e-9)) < 1e-8
+    eng.close()
