@@ -33,30 +33,52 @@ BYTES_PER_ROLLOUT = 8 * (4 * 2 * CARS * H + 4)      # 3232 B (Σ-ad
 FLOPS_PER_ROLLOUT = 3.5e5 * CARS                    # SURVEY 8(d) reference-algorithm flop-equivalents
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The oracle (C restatement, OpenMP over k like Threads.@threads :269) on this box's host cores,
-    same workload: whole pol(env) steps of ONE trial, bounded to ~10-30 s of CPU work.  The thread count is
-    calibrated first (one step each at 8..all cores): on the GPU boxes more OpenMP threads than physical
-    cores available to the container make the oracle slower, and the fastest setting is the fair baseline."""
+def _oracle_policy(policy, cars, Kc, Nc, nthreads, **kw):
     import numpy as np
     from oracle import oracle as O
+    env = O.OracleEnv("car", cars, track=O.load_track())
+    kind = {"μΣaismppi": "musigmaaismppi"}.get(policy, policy)
+    pol = O.OraclePolicy(kind, env, Kc, H, lam=LAM, U0=np.zeros(2 * cars), cov=np.tile([0.0625, 0.1], cars), N=Nc, lam_ais=LAM_AIS,
+                         nthreads=nthreads, **kw)
+    return env, pol
+
+
+def _oracle_noise(cars, Kc, n_iter, step):
+    import numpy as np
+    from oracle import oracle as O
+    cs = 2 * cars * H
+    return np.stack([O.philox_normals(20240001, step, n, cs * Kc).reshape(Kc, cs) for n in range(n_iter)])
+
+
+def cpu_port(policy, cars, Kc, Nc, nthreads, budget_s, max_steps=256, **kw):
+    """The oracle (C restatement, OpenMP over k like Threads.@threads :269) on this box's host cores: whole pol(env) steps of ONE trial
+    of the given config (the reference's own usage), bounded by budget_s seconds / max_steps steps."""
+    n_iter = 1 if policy == "gmppi" else Nc
+    env, pol = _oracle_policy(policy, cars, Kc, Nc, nthreads, **kw)
+    steps, t_total, rollouts = 0, 0.0, 0
+    while True:
+        Z = _oracle_noise(cars, Kc, n_iter, steps)
+        t0 = time.perf_counter()
+        r = pol(env, Z)
+        t_total += time.perf_counter() - t0
+        if r["status"] != 0:
+            break
+        steps += 1
+        rollouts += int(r["iters_run"]) * Kc
+        if t_total >= budget_s or steps >= max_steps:
+            break
+    return {"rollouts_per_s": rollouts / max(t_total, 1e-9), "mpc_steps_per_s": steps / max(t_total, 1e-9), "steps": steps, "seconds": t_total, "threads": nthreads}
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The oracle on this box's host cores, headline workload: whole pol(env) steps of ONE trial, bounded to ~10-30 s of CPU work.  The thread
+    count is calibrated first (one step each at 8..all cores): on the GPU boxes more OpenMP threads than physical cores available to the
+    container make the oracle slower, and the fastest setting is the fair baseline."""
     ncpu = os.cpu_count() or 1
-    track = O.load_track()
-    cs = 2 * CARS * H
-
-    def make(nthreads):
-        env = O.OracleEnv("car", CARS, track=track)
-        pol = O.OraclePolicy("musigmaaismppi", env, K, H, lam=LAM, U0=np.zeros(2 * CARS), cov=np.tile([0.0625, 0.1], CARS),
-                             N=N_AIS, lam_ais=LAM_AIS, nthreads=nthreads)
-        return env, pol
-
-    def noise(step):
-        return np.stack([O.philox_normals(20240001, step, n, cs * K).reshape(K, cs) for n in range(N_AIS)])
-
-    Z0 = noise(0)
+    Z0 = _oracle_noise(CARS, K, N_AIS, 0)
     best_t, best_n, t_cal = None, 1, 0.0
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)}):
-        env, pol = make(nt)
+        env, pol = _oracle_policy("μΣaismppi", CARS, K, N_AIS, nt)
         t0 = time.perf_counter()
         pol(env, Z0)
         dt = time.perf_counter() - t0
@@ -65,28 +87,26 @@ def cpu_baseline(seconds_target=12.0):
             best_t, best_n = dt, nt
         if dt > 4 * best_t:
             break
-    env, pol = make(best_n)
-    steps, t_total = 0, 0.0
-    while True:
-        Z = noise(steps)
-        t0 = time.perf_counter()
-        r = pol(env, Z)
-        t_total += time.perf_counter() - t0
-        assert r["status"] == 0
-        steps += 1
-        if t_total >= max(2.0, seconds_target - t_cal) or steps >= 256:
-            break
-    rollouts = steps * N_AIS * K
+    r = cpu_port("μΣaismppi", CARS, K, N_AIS, best_n, max(2.0, seconds_target - t_cal))
     # BASELINE.md section 4 also asks for the 1-thread figure: one MPC step of the same trial on a single core
-    env1, pol1 = make(1)
+    env1, pol1 = _oracle_policy("μΣaismppi", CARS, K, N_AIS, 1)
     t0 = time.perf_counter()
     pol1(env1, Z0)
     t_one = time.perf_counter() - t0
-    return {"value": rollouts / t_total, "unit": "rollouts/s", "cores": best_n, "kind": "port",
+    return {"value": r["rollouts_per_s"], "unit": "rollouts/s", "cores": best_n, "kind": "port",
             "value_1thread": N_AIS * K / t_one, "sample_1thread": "1 MPC step of 1 trial (%d rollouts), 1 thread, %.1f s" % (N_AIS * K, t_one),
             "sample": "%d MPC step(s) of 1 trial, same config (%d rollouts), C oracle + OpenMP over k, %.1f s (+%.1f s calibrating the thread count; host reports %d CPUs)"
-                      % (steps, rollouts, t_total, t_cal, ncpu),
-            "mpc_steps_per_s": steps / t_total}
+                      % (r["steps"], r["steps"] * N_AIS * K, r["seconds"], t_cal, ncpu),
+            "mpc_steps_per_s": r["mpc_steps_per_s"]}
+
+
+def cpu_configs(nthreads):
+    """CPU rows of BASELINE.md section 5's table for C2, C3, C4: one trial each (the reference's own usage), bounded samples."""
+    out = {}
+    out["C2"] = cpu_port("gmppi", 1, 1024, 1, nthreads, 1.0)
+    out["C3"] = cpu_port("cemppi", 1, 150, 10, nthreads, 1.5, sigma_est="ss", elite_threshold=0.8)
+    out["C4"] = cpu_port("cmamppi", 3, 4096, 10, nthreads, 4.0, max_steps=2, elite_threshold=0.8, cma_sigma=0.75)
+    return out
 
 
 def alg_bytes(policy, cs):
@@ -128,11 +148,15 @@ def measure_config(name, policy, cars, Kc, Nc, trials, steps, device, closed_loo
         eng.close()
     per_step = {k: v[0] / tsteps for k, v in tm.items() if v[1]}
     dom = max(per_step, key=per_step.get)
+    overlap = sum(per_step.values()) / (ms / steps)
     rps = rollouts / (ms * 1e-3)
     ba = alg_bytes(policy, cs)
     return {"config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
             "loop": "closed loop (mpopis_run_trials)" if closed_loop else "policy steps (mpopis_bench_policy_steps)",
             "kernel_ms_per_step": per_step, "dominant": {"class": dom, "avg_launch_us": tm[dom][0] / tm[dom][1] * 1e3, "share_of_kernel_time": per_step[dom] / sum(per_step.values())},
+            "kernel_time_over_step_time": overlap,
+            "schedule": ("multi-stream (the engine's automatic four-part schedule for this shape): kernel classes of different part-chains overlap, "
+                         "their times are summed over the streams and per-launch durations include time-sharing") if overlap > 1.2 else "one stream",
             "alg_bytes_per_rollout": ba, "hbm_frac": rps * ba / (HBM_PEAK_GBS * 1e9), "fp64_reference_algorithm_frac": rps * 3.5e5 * cars / (FP64_PEAK_TFLOPS * 1e12)}
 
 
@@ -380,7 +404,7 @@ def main():
             "repeats": {"n": len(samples), "what": "the timed region repeated back to back (first sample = the contract's timed region = `value`)",
                         "ms_per_step": {"median": med / args.steps * 1e3, "min": srt[0] / args.steps * 1e3, "max": srt[-1] / args.steps * 1e3},
                         "value": {"median": total_rollouts / med, "max": total_rollouts / srt[0], "min": total_rollouts / srt[-1]}},
-            "roofline": {"bound": "fp64_valu", "contract_bound": "hbm", "kernel": "k_rollout_car<1, 4, false>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "fp64_valu", "contract_bound": "hbm", "kernel": "k_rollout_car<1, 4, false, true>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_definition": "contract formula: whole-path algorithmic bytes per launch (SURVEY 8d: %d B x rollouts per launch) / the dominant kernel's average launch time / 8 TB/s" % BYTES_PER_ROLLOUT,
                          "what_binds": "FP64 VALU issue of the rollout kernel (HBM is at kernel_traffic_frac of peak: nothing is re-read; no MFMA in this kernel)",
@@ -406,6 +430,10 @@ def main():
             out["configs"] = baseline_configs(local_rank, quick=args.quick_configs)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            if "configs" in out and not args.quick_configs:
+                cpu = cpu_configs(out["cpu_baseline"]["cores"])                      # CPU rows of the same table, one trial each
+                for c in out["configs"]:
+                    c["cpu_one_trial"] = cpu[c["config"][:2]]
         print(json.dumps(out, ensure_ascii=False))
     eng.close()
     if dist is not None:
