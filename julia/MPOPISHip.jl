@@ -20,6 +20,11 @@ import MPOPIS: simulate_model
 
 const LIB = get(ENV, "MPOPIS_HIP_LIB", joinpath(@__DIR__, "..", "mpopis_amd", "lib", "libmpopis_hip.so"))
 
+function __init__()
+    v = ccall((:mpopis_abi_version, LIB), Cint, ())
+    v >= 2 || error("libmpopis_hip.so speaks ABI version $v; this binding needs >= 2 (mpopis_seed_slots, mpopis_get_Sigma, MPOPIS_ERR_NUMERIC)")
+end
+
 # mirrors `mpopis_config` (include/mpopis.h) field for field
 struct Config
     device::Int32; env_kind::Int32; num_cars::Int32; policy::Int32
@@ -145,7 +150,11 @@ for E in (:CarRacingEnv, :MultiCarRacingEnv, :MountainCarEnv, :CartPoleEnv)
         hip_simulate_model(pol, env, E, Σ_inv, U_orig)
 end
 
-# Random.seed!(pol, seed) also reseeds the device streams
+# Random.seed!(pol, seed) also reseeds the device streams.  NOTE for the maintainer: once a policy is bound to a handle, E is drawn on the device
+# from Philox4x32-10 streams keyed by this seed (slot b of a handle draws from seed + b, hence `seed - 1` below for the one-slot handles this
+# binding creates: mpopis_seed gives slot 0 the key `arg + 1`), NOT from `pol.rng`; `pol.rng` is still seeded so that code which reads it
+# directly (state noise in the example harness) behaves as before.  Results therefore differ from a CPU run with the same seed in the draws,
+# not in the algorithm -- pass explicit noise (`mpopis_noise`) to compare the two paths number for number.
 function MPOPIS.seed!(pol::AbstractPathIntegralPolicy, seed::Integer)
     MPOPIS.Random.seed!(pol.rng, seed)
     haskey(HANDLES, pol) && check(HANDLES[pol], ccall((:mpopis_seed, LIB), Cint, (Ptr{Cvoid}, UInt64), HANDLES[pol], UInt64(seed - 1)))
