@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmpopis_hip.so")
 SOURCES = ["engine_api.hip", "engine_ais.hip", "engine_harness.hip", "engine_comm.hip", "kernels_rollout.hip", "kernels_reweight.hip",
-           "kernels_sample.hip", "kernels_linalg.hip", "kernels_select.hip", "kernels_cma.hip", "kernels_invsqrt.hip", "kernels_mfma.hip"]
+           "kernels_sample.hip", "kernels_linalg.hip", "kernels_select.hip", "kernels_ce.hip", "kernels_cma.hip", "kernels_invsqrt.hip", "kernels_mfma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 

@@ -184,6 +184,11 @@ void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, d
 void launch_gather_mean_strided(const double* X, const int32_t* idx, const double* cw, double* out, size_t out_stride, int B, int cs, int K, int m,
                                 const int* active, hipStream_t s);
 
+// kernels_ce.hip: the whole CE proposal update (elite mean, Σ_est covariance + ridge, pol.U += μ′) in one launch for small elite sets
+bool ce_cov_small_ok(int cs, int m, int est);
+void launch_ce_cov_small(const double* E, const int32_t* order, double* mu, double* S, double* Ucur, int B, int cs, int K, int m, int est, double ridge,
+                         const int* active, hipStream_t s);
+
 // kernels_select.hip
 void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s);   // + elite early break
 void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws = nullptr);

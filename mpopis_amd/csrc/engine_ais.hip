@@ -128,6 +128,13 @@ int mpopis_handle::ais_update(int n, bool injected) {
         launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream);                    // :455 / :563 and the early break :458-461 / :566-569
         time_end();
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
+            static const int env_small = [] { const char* e = getenv("MPOPIS_CE_SMALL"); return e ? atoi(e) : 1; }();      // 0: always the general path (A/B, tests)
+            if (env_small && ce_cov_small_ok(cs, m_elite, cfg.sigma_est)) {
+                time_begin(4);
+                launch_ce_cov_small(d_E, d_order, d_mu, d_Sig, d_Ucur, B, cs, K, m_elite, cfg.sigma_est, 10e-9, d_active, stream);
+                time_end();
+                return MPOPIS_OK;
+            }
             time_begin(4);
             launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
             if (cfg.sigma_est == MPOPIS_SIGMA_EST_RBLW || cfg.sigma_est == MPOPIS_SIGMA_EST_OAS) {   // DiagonalCommonVariance :421-423

@@ -468,12 +468,13 @@ def test_level3_run_trials_cartpole(eng_mod, oracle, kind):
     eng.close()
 
 
-@pytest.mark.parametrize("est", ["ss", "lw", "rblw", "oas"])
-def test_level2_cemppi_shrinkage_estimators(eng_mod, oracle, track, est):
+@pytest.mark.parametrize("K", [150, 400])        # m_elite = 30: the one-launch small-elite kernel (kernels_ce.hip); 80: the general scatter path
+@pytest.mark.parametrize("est", ["mle", "ss", "lw", "rblw", "oas"])
+def test_level2_cemppi_shrinkage_estimators(eng_mod, oracle, track, est, K):
     """CEMPPI with the LinearShrinkage estimators (:ss is the car harness default, src/examples/car_example.jl:66): device
     shrinkage vs the oracle's restatement (third-party CovarianceEstimation.jl formulas, unpinned on both sides)."""
     rng = np.random.default_rng(17)
-    K, T, N = 150, 12, 4
+    T, N = 12, 4
     cs = 2 * T
     env = oracle.OracleEnv("car", 1, track=track)
     pol = oracle.OraclePolicy("cemppi", env, K, T, lam=10.0, U0=[0.0, 0.0], cov=[0.0625, 0.1], N=N, elite_threshold=0.8, sigma_est=est)
