@@ -134,6 +134,18 @@ MP_HD double clampd_u(double v, double lo, double hi) {
 #endif
 }
 
+// clampd for per-lane bounds in vector registers (multi-car kernel: the bounds differ between the cars of a wave): as clampd_u
+MP_HD double clampd_v(double v, double lo, double hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double t, r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(t) : "v"(v), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(lo));
+    return (v != v) ? v : r;
+#else
+    return clampd(v, lo, hi);
+#endif
+}
+
 // one Newton step on the v_rcp_f64 seed: <= 19 ulp (2.1e-15, measured in tools/rcp_acc.hip) -- used only for the slip tangents
 // of the hot sub-step, where the result feeds a cubic whose own evaluation carries a comparable rounding error
 MP_HD double fast_rcp1(double v) {

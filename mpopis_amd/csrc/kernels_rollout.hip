@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
             u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
         }
         if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
-        const double a0 = clampd(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd(v1, sh_bnd[c][2], sh_bnd[c][3]);   // get_model_controls (NaN passes through)
+        const double a0 = clampd_v(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd_v(v1, sh_bnd[c][2], sh_bnd[c][3]);   // get_model_controls (NaN passes through)
         car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
 #pragma unroll
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
             const double xq = __shfl(s.x, q * S + j, 64), yq = __shfl(s.y, q * S + j, 64);
             if (q > c) {
                 const double dx = xq - s.x, dy = yq - s.y;
-                const double dd = sqrt(dx * dx + dy * dy);
+                const double dd = fast_sqrt(dx * dx + dy * dy);                // 1 ulp (car_dynamics.h); coincident cars give 1e-150, not 0
                 rew += -dd;
                 if (dd <= 4.0) rew += -11000.0;
             }

@@ -27,4 +27,5 @@ if __name__ == "__main__":
     if which in ("all", "c4"): run("cmamppi", 4096, 50, 1, ncars=3); run("cmamppi", 4096, 50, 8, ncars=3)
     if which in ("all", "c5"): run("musigmaaismppi", 4096, 50, 8); run("musigmaaismppi", 4096, 50, 64)
     if which in ("all", "pmc"): run("pmcmppi", 4096, 50, 8)
+    if which in ("all", "mc3"): run("musigmaaismppi", 4096, 50, 32, ncars=3, N=4)          # multi-car rollout kernel at a chip-filling batch
     if which in ("all", "mu"): run("muaismppi", 4096, 50, 64)
