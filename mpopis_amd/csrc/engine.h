@@ -169,14 +169,14 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
                       const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr, const double* wsum = nullptr,
-                      const double* cost = nullptr, unsigned long long* cmin = nullptr, double neg_inv_lambda = 0.0);
+                      const double* cost = nullptr, unsigned long long* cmin = nullptr, double neg_inv_lambda = 0.0, const double* mu_shift = nullptr);
 bool wcov_weights_from_cost_ok(int cs, int K, int ksplit);
 bool wcov_mfma_can_emit_mean(int cs);
 void launch_inv_sd(const double* S, double* rs, int B, int cs, const int* active, hipStream_t s);
 void launch_common_shrink(double* S, int B, int cs, int m, int oas, double ridge, const int* active, hipStream_t s);
 void launch_fill_f64(double* p, double v, size_t n, hipStream_t s);
 void launch_ss_shrink(double* S, const double* Q, double* rs_ws, int B, int cs, int m, double ridge, const int* active, hipStream_t s);
-void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s);
+void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s, double* shift = nullptr);
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s);
 

@@ -100,9 +100,11 @@ int mpopis_handle::ais_update(int n, bool injected) {
         if (wcov_mfma_can_emit_mean(cs)) {
             // E′ = E[:, idx] materialised once (d_Z is free between two sampling phases; the Z prefetch is off for this policy), then
             // (μ′, Σ′) = mean_and_cov(E′, 2) (corrected, :807) in ONE pass over the contiguous E′: ones row for the mean, no per-element gather
-            launch_gather_cols(d_E, d_order, d_Z, B, cs, K, d_active, stream);
+            // (shifted by its first column -- d_gvec is free here: γ's row is rebuilt per iteration -- so that the one-pass moments do not cancel
+            // when the resampled set collapses onto a few columns; the finish kernel adds the shift back to μ′)
+            launch_gather_cols(d_E, d_order, d_Z, B, cs, K, d_active, stream, d_gvec);
             launch_wcov_mfma(d_Z, nullptr, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream, nullptr,
-                             d_mu, d_Ucur);                                                    // also pol.U += μ′ (:809)
+                             d_mu, d_Ucur, nullptr, nullptr, nullptr, 0.0, d_gvec);            // also pol.U += μ′ (:809)
             time_end();
             return MPOPIS_OK;
         }

@@ -595,14 +595,21 @@ __global__ void __launch_bounds__(256) k_gather_mean(const double* __restrict__ 
 }
 // Xout[b][r][k] = X[b][r][idx[b][k]]: E′ = E[:, idx] (:806) as a contiguous matrix (coalesced index reads and writes; the random reads stay inside
 // one 8K-byte row), so that the moments of the resampled columns run through the un-gathered fast path of the scatter kernel
+// shift (nullable, [B][cs]): the first resampled column E′[:, 1] is subtracted from every column and stored there.  Mean and covariance of the
+// shifted data are those of E′ up to adding the shift back to the mean (the caller does), and the one-pass moments (Σ x x' - n μ μ')/(n - 1) then
+// cancel against a small mean even when the resampled set collapses onto a few distinct columns far from the origin -- the reference's
+// mean_and_cov (:807) centres before it squares.
 __global__ void __launch_bounds__(256) k_gather_cols(const double* __restrict__ X, const int32_t* __restrict__ idx, double* __restrict__ Xout, int cs, int K,
-                                                     const int* active) {
+                                                     const int* active, double* __restrict__ shift) {
     const int b = blockIdx.z, r = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if ((active && !active[b]) || k >= K) return;
-    Xout[((size_t)b * cs + r) * K + k] = X[((size_t)b * cs + r) * K + idx[(size_t)b * K + k]];
+    const double* xr = X + ((size_t)b * cs + r) * K;
+    const double x0 = shift ? xr[idx[(size_t)b * K]] : 0.0;
+    if (shift && k == 0) shift[(size_t)b * cs + r] = x0;
+    Xout[((size_t)b * cs + r) * K + k] = xr[idx[(size_t)b * K + k]] - x0;
 }
-void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_cols, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, X, idx, Xout, cs, K, active);
+void launch_gather_cols(const double* X, const int32_t* idx, double* Xout, int B, int cs, int K, const int* active, hipStream_t s, double* shift) {
+    hipLaunchKernelGGL(k_gather_cols, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, X, idx, Xout, cs, K, active, shift);
 }
 void launch_gather_mean(const double* X, const int32_t* idx, const double* cw, double* mu, int B, int cs, int K, int m, int divide,
                         const int* active, hipStream_t s) {

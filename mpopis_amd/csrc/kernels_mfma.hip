@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
                                                           int cs, int K, int ksplit, int npairs, double den, double ridge, const int* active,
                                                           const double* __restrict__ mu_corr, double wtot_unweighted,
                                                           double* __restrict__ mu_aug, double* __restrict__ u_add, const double* __restrict__ wsum,
-                                                          unsigned long long* cmin_reset) {
+                                                          unsigned long long* cmin_reset, const double* __restrict__ mu_shift) {
     MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
@@ -333,8 +333,9 @@ __global__ void __launch_bounds__(256) k_wcov_mfma_finish(const double* __restri
             const double m = msum / swtot;
             smu[threadIdx.x] = m;
             if (ta == taug && threadIdx.x >= 16 && tb * 16 + jl < cs) {
-                mu_aug[(size_t)b * cs + tb * 16 + jl] = m;
-                if (u_add) u_add[(size_t)b * cs + tb * 16 + jl] += m;          // pol.U += μ′ (:734), one writer per entry
+                const double mfull = mu_shift ? m + mu_shift[(size_t)b * cs + tb * 16 + jl] : m;      // data were shifted by mu_shift (launch_gather_cols): Σ′ is unaffected
+                mu_aug[(size_t)b * cs + tb * 16 + jl] = mfull;
+                if (u_add) u_add[(size_t)b * cs + tb * 16 + jl] += mfull;      // pol.U += μ′ (:734), one writer per entry
             }
         }
         __syncthreads();
@@ -444,7 +445,8 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
 bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
-                      double* mu_out, double* u_add, const double* wsum, const double* cost, unsigned long long* cmin, double neg_inv_lambda) {
+                      double* mu_out, double* u_add, const double* wsum, const double* cost, unsigned long long* cmin, double neg_inv_lambda,
+                      const double* mu_shift) {
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
     const bool from_cost = cost && cmin && aug && !idx && wcov_weights_from_cost_ok(cs, K, ksplit);
     if (!from_cost) { cost = nullptr; cmin = nullptr; }
@@ -466,7 +468,7 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
-                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr, wsum, cmin);
+                       rscale ? (const double*)nullptr : mu, (double)m, aug ? mu_out : (double*)nullptr, aug ? u_add : (double*)nullptr, wsum, cmin, aug ? mu_shift : (const double*)nullptr);
 }
 // the weights-from-costs form needs the ones row (cs not a multiple of 16) and keeps a split's weights in LDS
 bool wcov_weights_from_cost_ok(int cs, int K, int ksplit) {
