@@ -206,6 +206,7 @@ def main():
     # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-gpu", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): rank 0 prints {\"launch_check\": world}; used by the CPU test of the self-launch")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -217,6 +218,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: WORLD_SIZE (%d) != --gpus (%d): launch N ranks or none (bench.py spawns them itself)" % (world, args.gpus))
+    if args.launch_check:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": world, "n_gpus": args.gpus}))
+        return
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -67,3 +67,20 @@ def test_assemble_gathered_matches_the_torch_path_layout():
         assert np.array_equal(row[1:16], [100.0 * k + f for f in range(15)])
         assert row[16] == 0.0 and row[17] == 7.0 + (k - 1) % world
     assert assemble_gathered([np.zeros((0, RECORD_LEN))] * 2, 2).shape == (0, RECORD_LEN + 2)
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver starts it (no torchrun, no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run
+    with two ranks; --launch-check stops after the rendezvous (gloo, no GPU), rank 0 prints the only JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-check"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": 2, "n_gpus": 2}, out.stdout[-500:]
+    # under a launcher that disagrees with --gpus the bench refuses with a message, not an assert
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=120, env=env2, cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in bad.stderr
