@@ -202,7 +202,7 @@ size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot = 1);
 int invsqrt_coop_groups(int B, int n, int share = 1);      // workgroups per matrix the cooperative Lanczos would use for this batch (1: not cooperative)
 int invsqrt_max_n();
 size_t trtri_dinv_doubles(int B, int n);      // workspace: the inverses of the diagonal 16 x 16 blocks, [B][ceil(n/16)][256]
-void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv);
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio = true);
 void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
                             double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
                             int regions_per_slot = 1, const CoopCtx& coop = CoopCtx());

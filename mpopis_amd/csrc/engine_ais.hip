@@ -116,9 +116,9 @@ int mpopis_handle::ais_update(int n, bool injected) {
     }
     if (pol == MPOPIS_POL_CEMPPI || pol == MPOPIS_POL_CMAMPPI) {
         const bool side = side_free && pol == MPOPIS_POL_CMAMPPI;
-        if (side) {
+        if (side && !trtri_early) {
             // tr(Σ^-1) = σ² ||L^-1||_F² needs only L = chol(σ²Σ): a latency-bound kernel of a few workgroups, run beside the equally
-            // latency-bound sort / elite mean on the free second stream (beside the rollout it cost the rollout more than it saved)
+            // latency-bound sort / elite mean on the free second stream (large batches; small ones start it right behind the Cholesky)
             if (!fork_recorded) (void)hipEventRecord(ev_fork, stream);          // the Z prefetch may already have marked the point behind the rollout
             (void)hipStreamWaitEvent(xstream[0], ev_fork, 0);
             // (no `active` predicate on the side stream: launch_sortperm below clears active[b] for the early break concurrently; an

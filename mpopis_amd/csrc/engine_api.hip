@@ -719,6 +719,20 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
                          potrf_coop(), d_Lp, potrf_panel_doubles(cs));
             time_end();
             Lp = d_L; Lstride = nn;
+            // :cmamppi: tr(Σ^-1) = σ² ||L^-1||_F² of THIS iteration's update needs only the factor just computed -- start it now on the free second
+            // stream (low wave priority: it shares the chip with the sampler and the rollout, which at small batches leave most CUs idle), so that
+            // the Lanczos kernel of the update never waits for it.  It used to start behind the rollout, beside the sort, and part of it stayed on
+            // the critical path: C4 6.56 -> 5.98 ms per step at one trial, 8.25 -> 7.70 at 8, 11.2 -> 10.8 at 16, neutral from 32 on
+            // (MPOPIS_TRTRI_EARLY=0 restores the old placement for A/B runs).
+            static const int env_early = [] { const char* e = getenv("MPOPIS_TRTRI_EARLY"); return e ? atoi(e) : 1; }();
+            trtri_early = false;
+            if (env_early && pol == MPOPIS_POL_CMAMPPI && side_free && n < N) {
+                (void)hipEventRecord(ev_skew[2], stream);
+                (void)hipStreamWaitEvent(xstream[0], ev_skew[2], 0);
+                launch_trtri_fro(d_L, nn, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
+                (void)hipEventRecord(ev_join[0], xstream[0]);
+                trtri_early = true;
+            }
         }
         if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream);
         // ---- E = rand(rng, P, K) ----------------------------------------------------------------

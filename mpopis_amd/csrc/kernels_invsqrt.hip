@@ -64,8 +64,8 @@ __device__ __forceinline__ double ld_L(const double* __restrict__ L, int n, int 
 constexpr int kTriW = 2;                                          // waves per block column
 
 // dinv[b][I][i][k] = (L(I,I)^-1)[i][k], one wave per diagonal block
-__global__ void __launch_bounds__(64) k_trtri_diag(const double* __restrict__ Lall, size_t Lstride, int n, int nb, double* __restrict__ dinv, const int* active) {
-    MPOPIS_HI_PRIO();
+__global__ void __launch_bounds__(64) k_trtri_diag(const double* __restrict__ Lall, size_t Lstride, int n, int nb, double* __restrict__ dinv, const int* active, int hiprio) {
+    if (hiprio) MPOPIS_HI_PRIO();
     const int b = blockIdx.y, I = blockIdx.x;
     if (active && !active[b]) return;
     __shared__ double Ld[256], Di[256];
@@ -98,8 +98,8 @@ typedef double v4f64_t __attribute__((ext_vector_type(4)));
 // and block instead of 16), Bm' = X(K) from LDS (row-major: Bm[j][k] = X[k][j] is the read Xs[(4kk + lk) 16 + li]).
 template <int W>
 __global__ void __launch_bounds__(128 * W) k_trtri_fro_pair(const double* __restrict__ Lall, size_t Lstride, int n, int nb, const double* __restrict__ dinv,
-                                                            double* __restrict__ part, const int* active) {
-    MPOPIS_HI_PRIO();
+                                                            double* __restrict__ part, const int* active, int hiprio) {
+    if (hiprio) MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh_tri[];
@@ -521,13 +521,14 @@ int invsqrt_max_n() {
 // A must stay readable for kInvsqrtPadDoubles doubles behind its last slot (the mat-vec reads whole 64-row chunks).
 // part[b][nb] = per-block-column partial sums of ||L^-1||_F^2 (only L is read: may run on another stream beside the sort / elite mean)
 size_t trtri_dinv_doubles(int B, int n) { return (size_t)B * ((n + kTB - 1) / kTB) * 256; }
-void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv) {
+// hiprio = false: the launch runs beside a throughput kernel of the same handle (the rollout) and must not take its issue slots
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio) {
     const int nb = (n + kTB - 1) / kTB;
     const size_t lds = ((size_t)(nb + 1) * 256 + 2 * kTriW * 256 + 2 * kTriW) * sizeof(double);
     static std::atomic<unsigned long long> seenp{0};
     ensure_dyn_lds((const void*)k_trtri_fro_pair<kTriW>, 150 * 1024, seenp);
-    hipLaunchKernelGGL(k_trtri_diag, dim3(nb, B), dim3(64), 0, s, L, Lstride, n, nb, dinv, active);
-    hipLaunchKernelGGL(k_trtri_fro_pair<kTriW>, dim3((nb + 1) / 2, B), dim3(128 * kTriW), lds, s, L, Lstride, n, nb, dinv, part, active);
+    hipLaunchKernelGGL(k_trtri_diag, dim3(nb, B), dim3(64), 0, s, L, Lstride, n, nb, dinv, active, hiprio ? 1 : 0);
+    hipLaunchKernelGGL(k_trtri_fro_pair<kTriW>, dim3((nb + 1) / 2, B), dim3(128 * kTriW), lds, s, L, Lstride, n, nb, dinv, part, active, hiprio ? 1 : 0);
 }
 
 // y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound).
