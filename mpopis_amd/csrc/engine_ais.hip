@@ -127,7 +127,8 @@ int mpopis_handle::ais_update(int n, bool injected) {
             (void)hipEventRecord(ev_join[0], xstream[0]);
         }
         time_begin(5);
-        launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream);                    // :455 / :563 and the early break :458-461 / :566-569
+        // (:pmcmppi's alias-table buffers are free under :cemppi / :cmamppi: scratch of the chip-wide rank sort)
+        launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream, d_accept, d_alias_need);   // :455 / :563 and the early break :458-461 / :566-569
         time_end();
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
             static const int env_small = [] { const char* e = getenv("MPOPIS_CE_SMALL"); return e ? atoi(e) : 1; }();      // 0: always the general path (A/B, tests)

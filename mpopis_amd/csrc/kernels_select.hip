@@ -152,9 +152,84 @@ __global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict_
     elite_break_tail(sc, m_elite, active, b);
 }
 
-// order = sortperm(cost) per slot, and (m_elite >= 2) the elite early-break check on the sorted costs
-void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s) {
+// Large K at a few slots (C4: K = 4096, 1-16 trials): the bitonic network above is one workgroup per slot and ~49 us of pure latency (78 dependent
+// compare-exchange steps) on a chip that is otherwise idle.  Rank sort across the whole chip instead: K^2 independent comparisons.  A workgroup owns
+// kRmE = 16 entries; thread (el, js) counts how many entries of the js-th sixteenth of the slot precede entry el in the (cost, index) order (all K costs
+// in LDS: broadcast reads), the 16 partial counts are added, and order[rank] = entry -- the same permutation as the stable sort, by construction.
+// The elite early break needs the sorted costs: every workgroup publishes skey[rank] for rank < m_elite (agent-scope stores), and the LAST workgroup
+// of the slot to finish (a per-slot arrival counter) evaluates max |diff| -- one launch, no host round trip.  Work grows with B K^2: used for one or two slots.
+constexpr int kRmE = 16;
+__global__ void __launch_bounds__(256) k_sortperm_rank_multi(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int m_elite, int* active,
+                                                             double* __restrict__ skey, int* __restrict__ done) {
+    MPOPIS_HI_PRIO();
+    extern __shared__ __attribute__((aligned(16))) double c_l[];            // [K]
+    __shared__ int sh_rank[kRmE];
+    __shared__ int sh_last;
+    __shared__ double eb[4];
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, el = tid & (kRmE - 1), js = tid >> 4;
+    for (int j = tid; j < K; j += 256) c_l[j] = cost[(size_t)b * K + j];
+    if (tid < kRmE) sh_rank[tid] = 0;
+    __syncthreads();
+    const int e = blockIdx.x * kRmE + el;
+    const double ce = (e < K) ? c_l[e] : INFINITY;
+    const int JR = ((K + 15) / 16 + 3) & ~3, j0 = js * JR, j1 = min(K, j0 + JR);
+    int cnt = 0;
+    int j = j0;
+    for (; j + 4 <= j1; j += 4) {
+        const double c0 = c_l[j], c1 = c_l[j + 1], c2 = c_l[j + 2], c3 = c_l[j + 3];
+        cnt += ((c0 < ce) || (c0 == ce && j < e)) + ((c1 < ce) || (c1 == ce && j + 1 < e)) + ((c2 < ce) || (c2 == ce && j + 2 < e)) +
+               ((c3 < ce) || (c3 == ce && j + 3 < e));
+    }
+    for (; j < j1; ++j) cnt += ((c_l[j] < ce) || (c_l[j] == ce && j < e));
+    cnt += __shfl_xor(cnt, 16, 64);                                           // the four js values of this wave
+    cnt += __shfl_xor(cnt, 32, 64);
+    if ((tid & 63) < kRmE) atomicAdd(&sh_rank[el], cnt);                      // ... and the four waves
+    __syncthreads();
+    if (tid < kRmE && e < K) {
+        const int rank = sh_rank[el];
+        order[(size_t)b * K + rank] = e;
+        if (rank < m_elite) __hip_atomic_store((unsigned long long*)&skey[(size_t)b * K + rank], (unsigned long long)__double_as_longlong(ce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (m_elite < 2 || !active) return;
+    // ---- elite early break (:458-461 / :566-569) by the last workgroup of the slot -------------------------------------------------------------
+    // (no fence: the skey entries are write-through agent-scope stores, drained before this workgroup's arrival is counted, and read back with
+    // agent-scope loads -- an agent-scope fence would write back the XCD's whole L2 once per workgroup)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sh_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!sh_last) return;
+    double mx = -INFINITY;
+    for (int q = tid; q + 1 < m_elite; q += 256) {
+        const double a0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double a1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mx = fmax(mx, fabs(a1 - a0));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) eb[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        mx = fmax(fmax(eb[0], eb[1]), fmax(eb[2], eb[3]));
+        if (mx < 10e-3) active[b] = 0;
+        done[b] = 0;                                                          // ready for the next launch (stream order)
+    }
+}
+
+// order = sortperm(cost) per slot, and (m_elite >= 2) the elite early-break check on the sorted costs.
+// skey ([B][K] doubles) / done ([B] ints, zero between launches): workspace of the chip-wide rank sort (nullptr: never used)
+void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s, double* skey, int* done) {
     if (K <= 256) { hipLaunchKernelGGL(k_sortperm_rank, dim3(B), dim3(256), 0, s, cost, order, K, m_elite, active); return; }
+    static const int env_rm = [] { const char* e = getenv("MPOPIS_SORT_MULTI"); return e ? atoi(e) : 1; }();       // 0: bitonic only (A/B)
+    // measured, C4 (K = 4096): 49.5 -> 20.5 us per sort at one slot (step 5.97 -> 5.72 ms); at 8 slots 52 vs ~60 us, at 16 worse -- so: few slots only
+    if (env_rm && skey && done && K >= 2048 && (long long)B * K * K <= 2ll * 4096 * 4096) {
+        static std::atomic<unsigned long long> seenm{0};
+        ensure_dyn_lds((const void*)k_sortperm_rank_multi, 96 * 1024, seenm);
+        hipLaunchKernelGGL(k_sortperm_rank_multi, dim3((K + kRmE - 1) / kRmE, B), dim3(256), (size_t)K * sizeof(double), s, cost, order, K, m_elite, active, skey, done);
+        return;
+    }
     int n = 512;
     while (n < K) n <<= 1;
     const size_t bytes = (size_t)n * (sizeof(double) + sizeof(int32_t));

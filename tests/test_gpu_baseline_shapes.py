@@ -276,6 +276,15 @@ def test_cooperative_cholesky_cs300(eng_mod, track):
     assert np.max(np.abs(outs[0][0] - outs[1][0])) < 1e-9 and rel_err(outs[0][1], outs[1][1]) < 1e-9
 
 
+def test_chipwide_rank_sort_K4096_one_slot(eng_mod, oracle, track):
+    """K = 4096 at ONE slot takes the chip-wide rank sort (k_sortperm_rank_multi: K^2 comparisons over 256 workgroups, early break by the last
+    workgroup to finish) instead of the one-workgroup bitonic network the 2-slot cases of this file use: :cemppi and :cmamppi against the oracle,
+    which needs the identical permutation (elite set, CMA rank weights) and the identical early-break decision."""
+    run_case(eng_mod, oracle, track, "cemppi", 1, 4096, 50, 4, B=1, steps=2, sigma_est="mle")
+    run_case(eng_mod, oracle, track, "cmamppi", 1, 4096, 20, 3, B=1, steps=1)
+    run_case(eng_mod, oracle, track, "cemppi", 1, 2048, 20, 6, B=2, steps=1, device_rng=True, sigma_est="ss")
+
+
 @pytest.mark.parametrize("K", [100, 300, 8192])
 def test_sortperm_sizes_through_cemppi(eng_mod, oracle, track, K):
     """order = sortperm(cost) (:455) has three device kernels: rank sort (K <= 256), the all-LDS bitonic network (n = 512, 1024) and the

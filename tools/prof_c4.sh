@@ -8,4 +8,4 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o c4 -- python "$R/tools/prof_c4.py" $B > "$O/prof.log" 2>&1
 tail -2 "$O/prof.log"
-head -14 "$O/prof/c4_kernel_stats.csv" | cut -c1-150; rm -f "$O"/prof/*kernel_trace.csv
+head -14 "$O/prof/c4_kernel_stats.csv" | cut -c1-150; python "$R/tools/trace_timeline.py" "$O/prof/c4_kernel_trace.csv" k_rollout 30 36 > "$O/timeline.txt" 2>&1; rm -f "$O"/prof/*kernel_trace.csv
