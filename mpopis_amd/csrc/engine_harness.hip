@@ -128,7 +128,9 @@ int mpopis_handle::run_trials(int num_steps, int laps, double* records, double* 
         if ((s & 7) == 7 || s == num_steps) {
             (void)hipMemcpyAsync(h_alive.data(), d_alive, sizeof(int) * B, hipMemcpyDeviceToHost, stream);
             (void)hipMemcpyAsync(h_status.data(), d_status, sizeof(int) * B, hipMemcpyDeviceToHost, stream);
+            if (h_coop_timeouts && !coop_disabled) (void)hipMemcpyAsync(h_coop_timeouts, d_coop_timeouts, sizeof(int), hipMemcpyDeviceToHost, stream);
             if (hipStreamSynchronize(stream) != hipSuccess) { err = "stream sync failed"; if (d_actlog) (void)hipFree(d_actlog); return MPOPIS_ERR_HIP; }
+            if (h_coop_timeouts && *h_coop_timeouts > 0) coop_disabled = true;   // a cluster gave up (and was redone): stop using clusters, also within this call
             for (int b = 0; b < B; ++b) worst = mpopis::worse_status(worst, h_status[b]);
             bool any = false;
             for (int b = 0; b < B; ++b) any |= h_alive[b] != 0;
