@@ -52,6 +52,18 @@ def test_engine_steps_survive_lost_partners():
     assert np.max(np.abs(np.array(none["control"]) - np.array(ref["control"]))) < 1e-8
 
 
+def test_closed_loop_survives_lost_partners_and_stops_using_clusters():
+    """mpopis_run_trials with every cluster losing a partner: the loop completes with status 0 and the same first actions as a healthy run; the time-out
+    counter is polled inside the loop (every 8 MPC steps), after which the handle runs the one-workgroup kernels (bounded total stall)."""
+    import time
+    ref = _run_case([2, 512, 1, 12])
+    t0 = time.time()
+    got = _run_case([2, 512, 1, 12], {"MPOPIS_COOP_TEST_DROP": "1", "MPOPIS_COOP_WAIT_US": "3000"})
+    assert all(s == 0.0 for s in got["loop_status"]) and all(s == 0.0 for s in ref["loop_status"])
+    assert np.max(np.abs(np.array(got["loop_actions"]) - np.array(ref["loop_actions"]))) < 1e-6
+    assert time.time() - t0 < 120
+
+
 def test_two_processes_share_one_device_cs300_cmamppi():
     """Two processes, one GPU, both with cooperative cs = 300 kernels in flight for 20 MPC steps: neither may report MPOPIS_ERR_HIP (-4)."""
     env = dict(os.environ)
