@@ -276,7 +276,13 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         return t;
     };
     double fro = 0.0;
-    for (int J = 0; J < nb; ++J) fro += part[(size_t)b * nb + J];
+    for (int J0 = 0; J0 < nb; J0 += 8) {                        // same summation order as a plain loop, but eight loads in flight (a plain loop waits
+        double t[8];                                            // for every load before the next addition: nb dependent L2 round trips)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)b * nb + min(J0 + u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (J0 + u < nb) fro += t[u];
+    }
     fro *= scale ? scale[b] : 1.0;
     if (tid == 0 && writer) fro_out[b] = fro;
     // ---- v_0 = b / ||b|| --------------------------------------------------------------------------------------------------
