@@ -378,6 +378,8 @@ int mpopis_set_Sigma(mpopis_handle* h, const double* Sigma, int32_t n) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     HIPCHK(h, hipMemcpyAsync(h->d_Sigma0, full.data(), sizeof(double) * cs * cs, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_dscale0, ds.data(), sizeof(double) * cs, hipMemcpyHostToDevice, h->stream));
+    // per-slot copy for the diagonal-Σ sampler, once per pol.Σ (it used to be re-broadcast by a launch of its own in every AIS iteration)
+    hipLaunchKernelGGL(k_bcast_f64, dim3((cs + 255) / 256), dim3(256), 0, h->stream, h->d_dscale0, h->d_dscale, (size_t)cs, h->B);
     // factor once: L0 (shared by all slots; the reference refactors the same Σ every call, :307)
     fill_i32(h->d_status, 0, h->B, h->stream);
     launch_potrf(h->d_Sigma0, 0, h->d_L0, 1, cs, nullptr, h->d_status, nullptr, h->stream, h->potrf_coop(), h->d_L0p, 0);
@@ -737,10 +739,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream);
         // ---- E = rand(rng, P, K) ----------------------------------------------------------------
         time_begin(1);
-        if (first_diag && !(pol == MPOPIS_POL_CMAMPPI)) {
-            hipLaunchKernelGGL(k_bcast_f64, dim3((cs + 255) / 256), dim3(256), 0, stream, d_dscale0, d_dscale, (size_t)cs, B);
-            dsc = d_dscale;
-        }
+        if (first_diag && !(pol == MPOPIS_POL_CMAMPPI)) dsc = d_dscale;        // sqrt(diag Σ) per slot, written by mpopis_set_Sigma
         double* Zdst = dsc ? d_E : d_Z;
         bool fused = false;
         if (injected) {
