@@ -158,13 +158,15 @@ constexpr int kPanelRows = 128;
 size_t potrf_panel_doubles(int n);
 void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, const double* scale, int* status, int* active, hipStream_t s,
                   const CoopCtx& coop = CoopCtx(), double* panel = nullptr, size_t pstride = 0);
-void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s);
+void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s,
+                            const double* inv_scale2 = nullptr);      // L = chol(Σ) while the proposal is MvNormal(s²Σ) (:cmamppi): g = (s²Σ)^-1 γU = Σ^-1 γU / s²
 void launch_gvec_from_inv(const double* Sinv, const double* Uorig, double gamma, double* g, int B, int n, hipStream_t s);
 // kernels_mfma.hip
-void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s);
+void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s,
+                         const double* oscale2 = nullptr);      // oscale2[b] (nullable): E = sqrt(oscale2[b]) L Z
 bool sample_trmm_fusable(int n);
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride);
+                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2 = nullptr);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
                       int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,

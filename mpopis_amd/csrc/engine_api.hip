@@ -714,16 +714,25 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         // ---- P = MvNormal(Σ′): Cholesky; Σ_inv only through gvec --------------------------------
         const double* Lp; size_t Lstride; const double* dsc = nullptr;
         const bool first_diag = sigma_diag && (sigma_fixed || n == 1);
-        if (sigma_fixed || (n == 1 && pol != MPOPIS_POL_CMAMPPI)) { Lp = d_L0; Lstride = 0; }
+        // :cmamppi draws from MvNormal(σ²Σ′) (:550-554).  In the first iteration Σ′ = pol.Σ and chol(σ²Σ′) = σ chol(pol.Σ): the shared factor of pol.Σ
+        // is used like for every other policy and the step size scales the sampler's output (osc2) -- one Cholesky less per MPC step (160 us at
+        // cs = 300).  From the second iteration on σ²Σ′ itself is factored, like the reference does: Σ′ drifts towards indefiniteness there
+        // (:598 adds negative-weight terms) and whether a last pivot of relative size 1e-16 comes out positive decides between PosDefException now and
+        // a numerically singular factor one iteration later -- factoring the unscaled Σ′ flipped exactly that in test_cma_posdef_error_matches_reference_behaviour.
+        const bool cma_scaled = pol == MPOPIS_POL_CMAMPPI && N > 1;
+        const double* osc2 = (cma_scaled && n == 1) ? cma_sigma2() : nullptr;
+        if (sigma_fixed || n == 1) { Lp = d_L0; Lstride = 0; }
         else {
             time_begin(2);
-            launch_potrf(d_Sig, nn, d_L, B, cs, (pol == MPOPIS_POL_CMAMPPI && N > 1) ? cma_sigma2() : nullptr, d_status, d_active, stream,
-                         potrf_coop(), d_Lp, potrf_panel_doubles(cs));
+            launch_potrf(d_Sig, nn, d_L, B, cs, cma_scaled ? cma_sigma2() : nullptr, d_status, d_active, stream, potrf_coop(), d_Lp, potrf_panel_doubles(cs));
             time_end();
             Lp = d_L; Lstride = nn;
-            // :cmamppi: tr(Σ^-1) = σ² ||L^-1||_F² of THIS iteration's update needs only the factor just computed -- start it now on the free second
-            // stream (low wave priority: it shares the chip with the sampler and the rollout, which at small batches leave most CUs idle), so that
-            // the Lanczos kernel of the update never waits for it.  It used to start behind the rollout, beside the sort, and part of it stayed on
+        }
+        cur_L = Lp; cur_Lstride = Lstride; cur_L_scaled = cma_scaled && n > 1;
+        {
+            // :cmamppi: tr(Σ^-1) (= ||L^-1||_F², times σ² when L factors σ²Σ) of THIS iteration's update needs only the factor this iteration samples from -- start it now on the free
+            // second stream (low wave priority: it shares the chip with the sampler and the rollout, which at small batches leave most CUs idle), so
+            // that the Lanczos kernel of the update never waits for it.  It used to start behind the rollout, beside the sort, and part of it stayed on
             // the critical path: C4 6.56 -> 5.98 ms per step at one trial, 8.25 -> 7.70 at 8, 11.2 -> 10.8 at 16, neutral from 32 on
             // (MPOPIS_TRTRI_EARLY=0 restores the old placement for A/B runs).
             static const int env_early = [] { const char* e = getenv("MPOPIS_TRTRI_EARLY"); return e ? atoi(e) : 1; }();
@@ -731,12 +740,12 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             if (env_early && pol == MPOPIS_POL_CMAMPPI && side_free && n < N) {
                 (void)hipEventRecord(ev_skew[2], stream);
                 (void)hipStreamWaitEvent(xstream[0], ev_skew[2], 0);
-                launch_trtri_fro(d_L, nn, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
+                launch_trtri_fro(Lp, Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
                 (void)hipEventRecord(ev_join[0], xstream[0]);
                 trtri_early = true;
             }
         }
-        if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream);
+        if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream, osc2);
         // ---- E = rand(rng, P, K) ----------------------------------------------------------------
         time_begin(1);
         if (first_diag && !(pol == MPOPIS_POL_CMAMPPI)) dsc = d_dscale;        // sqrt(diag Σ) per slot, written by mpopis_set_Sigma
@@ -755,12 +764,12 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         } else if (!dsc && pol != MPOPIS_POL_MPPI) {
             // dense proposal: draw inside the unwhitening kernel when the shape allows it (no Z round trip through HBM)
             fused = launch_sample_trmm_fused(Lp, Lstride, d_E, B, cs, K, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), d_active, stream, d_rng_tab,
-                                             Lstride ? d_Lp : d_L0p, Lstride ? potrf_panel_doubles(cs) : (size_t)0);
+                                             Lstride ? d_Lp : d_L0p, Lstride ? potrf_panel_doubles(cs) : (size_t)0, osc2);
             if (!fused) launch_sample_normal(Zdst, B, cs, K, as, 0, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream, d_rng_tab);
         } else {
             launch_sample_normal(Zdst, B, cs, K, as, pol == MPOPIS_POL_MPPI, d_seeds, (uint32_t)mpc_step, (uint32_t)(n - 1), dsc, d_active, stream, d_rng_tab);
         }
-        if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream);
+        if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream, osc2);
         time_end();
         if (n == 1 && record_after_first_sampler) (void)hipEventRecord(record_after_first_sampler, stream);   // the next part starts when this one enters its first rollout
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------

@@ -13,6 +13,8 @@ struct mpopis_handle {
     static constexpr int kMaxSplit = 4;
     hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
     bool split_pinned = false;   // MPOPIS_NSPLIT set: the schedule is fixed for the process
+    const double* cur_L = nullptr; size_t cur_Lstride = 0;   // the factor the current AIS iteration samples from (shared L0 or per-slot d_L)
+    bool cur_L_scaled = false;                               // ... factors σ²Σ′ (:cmamppi from the second iteration on) rather than Σ′
     bool trtri_early = false;    // this iteration's ||L^-1||_F launch already sits on xstream[0] (queued right behind the Cholesky)
     bool fork_recorded = false;  // ev_fork already recorded behind the current iteration's rollout
     bool side_free = false;      // batch not split this step: xstream[0] / ev_fork / ev_join[0] carry the CMA side chain (||L^-1||_F beside sort + elite mean)

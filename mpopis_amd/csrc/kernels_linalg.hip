@@ -525,7 +525,7 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
 // g = Σ⁻¹ (γ U_orig) through the Cholesky factor (Σ symmetric => row vector γ U_orig' Σ⁻¹ = g').
 // Slow path: only taken when α != 1 (γ != 0); no BASELINE config uses it.
 __global__ void __launch_bounds__(256) k_chol_solve_gvec(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Uorig,
-                                                         double gamma, double* __restrict__ g, int n, const int* active) {
+                                                         double gamma, double* __restrict__ g, int n, const int* active, const double* inv_scale2) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) double y[];
     const int b = blockIdx.x;
@@ -547,10 +547,12 @@ __global__ void __launch_bounds__(256) k_chol_solve_gvec(const double* __restric
         for (int i = threadIdx.x; i < j; i += 256) y[i] = fma(-Lb[(size_t)j + (size_t)i * n], yj, y[i]);
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < n; i += 256) g[(size_t)b * n + i] = y[i];
+    const double isc = inv_scale2 ? 1.0 / inv_scale2[b] : 1.0;
+    for (int i = threadIdx.x; i < n; i += 256) g[(size_t)b * n + i] = inv_scale2 ? y[i] * isc : y[i];
 }
-void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_chol_solve_gvec, dim3(B), dim3(256), n * sizeof(double), s, L, Lstride, Uorig, gamma, g, n, active);
+void launch_chol_solve_gvec(const double* L, size_t Lstride, const double* Uorig, double gamma, double* g, int B, int n, const int* active, hipStream_t s,
+                            const double* inv_scale2) {
+    hipLaunchKernelGGL(k_chol_solve_gvec, dim3(B), dim3(256), n * sizeof(double), s, L, Lstride, Uorig, gamma, g, n, active, inv_scale2);
 }
 
 // Level-1 entry: caller supplies Σ_inv; g[j] = Σ_i (γ U_orig[i]) Σ_inv[i][j]   (:272)

@@ -28,7 +28,9 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 //              current chunk from the Philox streams (same counters as k_sample_normal_pair, i.e. the same numbers), two
 //              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
 //              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
-struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; const double* panel; size_t pstride; };
+// oscale2 (nullable, [B]): E = sqrt(oscale2[b]) L Z -- :cmamppi draws from MvNormal(σ²Σ′) (:550-554) and keeps the factor of Σ′ itself: chol(σ²Σ′) = σ chol(Σ′),
+// so the step size only scales the output and the factorisation does not have to wait for it
+struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; const double* panel; size_t pstride; const double* oscale2; };
 // 4 waves per SIMD (128 VGPRs; the LDS panel allows 4 workgroups per CU): measured 5 % faster than the default 3 for the fused
 // sampler (Philox / Box-Muller VALU work of one wave fills the slots in which another waits on the matrix cores)
 template <bool RNG>
@@ -122,6 +124,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
         }
     }
+    const double osc = rng.oscale2 ? sqrt(rng.oscale2[b]) : 1.0;
     if (wave_on && k0 + li < K) {
 #pragma unroll
         for (int t = 0; t < kTrmmTiles; ++t) {
@@ -129,25 +132,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = (t0 + t) * 16 + lk + 4 * r;
-                    if (i < n) Eb[(size_t)i * K + k0 + li] = acc[t][r];
+                    if (i < n) Eb[(size_t)i * K + k0 + li] = rng.oscale2 ? osc * acc[t][r] : acc[t][r];
                 }
             }
         }
     }
 }
 
-void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s) {
+void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s, const double* oscale2) {
     const int nt = (n + 15) / 16;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       RngArgs{nullptr, 0, 0, nullptr, nullptr, 0});
+                       RngArgs{nullptr, 0, 0, nullptr, nullptr, 0, oscale2});
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
 bool sample_trmm_fusable(int n) { return !(n & 1) && (n + 15) / 16 <= kTrmmTiles; }
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
-                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride) {
+                              const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2) {
     if (!sample_trmm_fusable(n) || !panel) return false;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride});
+                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2});
     return true;
 }
 // ---------------------------------------------------------------------------------------------
