@@ -35,7 +35,7 @@ struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; co
 // sampler (Philox / Box-Muller VALU work of one wave fills the slots in which another waits on the matrix cores)
 template <bool RNG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
-                                                      double* __restrict__ E, int n, int K, const int* active, RngArgs rng) {
+                                                      double* __restrict__ E, int n, int K, const int* active, RngArgs rng, int tpg) {
     __shared__ double Ls[2][16][kTrmmLd];
     __shared__ double sh_tab[RNG ? kRngTabDoubles : 1];
     const int b = blockIdx.z;
@@ -43,9 +43,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (RNG) { stage_rng_tab(sh_tab, rng.tab, threadIdx.x, 256); __syncthreads(); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int k0 = (blockIdx.x * 4 + wv) * 16;
-    const int t0 = blockIdx.y * kTrmmTiles;                    // first row tile of this group
+    const int t0 = blockIdx.y * tpg;                           // first row tile of this group (tpg <= kTrmmTiles row tiles per group, balanced)
     const int nt_total = (n + 15) / 16;
-    const int nt = min(kTrmmTiles, nt_total - t0);
+    const int nt = min(tpg, nt_total - t0);
     const double* Lb = L + (size_t)b * Lstride;
     const double* Zb = Z + (size_t)b * n * K;
     double* Eb = E + (size_t)b * n * K;
@@ -140,9 +140,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 }
 
 void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, double* E, int B, int n, int K, const int* active, hipStream_t s, const double* oscale2) {
-    const int nt = (n + 15) / 16;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<false>), dim3((K + 63) / 64, (nt + kTrmmTiles - 1) / kTrmmTiles, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
-                       RngArgs{nullptr, 0, 0, nullptr, nullptr, 0, oscale2});
+    // row tiles dealt evenly to the row groups (19 tiles at n = 300: 7 / 7 / 5 instead of 8 / 8 / 3 -- the last group stages every chunk of L and Z
+    // for its few tiles, so a short group is mostly staging)
+    const int nt = (n + 15) / 16, ng = (nt + kTrmmTiles - 1) / kTrmmTiles, tpg = (nt + ng - 1) / ng;
+    hipLaunchKernelGGL((k_trmm_LZ_mfma<false>), dim3((K + 63) / 64, ng, B), dim3(256), 0, s, L, Lstride, Z, E, n, K, active,
+                       RngArgs{nullptr, 0, 0, nullptr, nullptr, 0, oscale2}, tpg);
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
 bool sample_trmm_fusable(int n) { return !(n & 1) && (n + 15) / 16 <= kTrmmTiles; }
@@ -150,7 +152,7 @@ bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B,
                               const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2) {
     if (!sample_trmm_fusable(n) || !panel) return false;
     hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2});
+                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2}, kTrmmTiles);
     return true;
 }
 // ---------------------------------------------------------------------------------------------
