@@ -114,6 +114,88 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
     }
 }
 
+// One car, few rollouts (the lone-wave regime: fewer waves than SIMDs -- one trial of K <= 4096, or the 8-trials-per-GPU share of a strong-scaled
+// run).  A wave alone on a SIMD issues one FP64 instruction per ~8.4 cycles whatever it does, so a rollout costs its instruction count and most
+// of the chip idles.  Here a workgroup is TWO waves for 64 samples: wave 0 integrates the dynamics (V = U + E, clamp, car_action_step) and hands
+// (x, y, Vx, Vy) after every model step to wave 1 through a two-slot LDS mailbox; wave 1 evaluates the reward (nearest-point search, lane test,
+// drift penalty: ~110 of the ~885 instructions of a model step) and accumulates the cost.  Same arithmetic in the same order as k_rollout_car --
+// bit-identical costs -- with the dynamics wave's chain 11 % shorter.  The mailbox is release / acquire at workgroup scope; the reward wave is
+// ~8x faster than the dynamics wave, so the producer practically never waits for a free slot.
+template <bool TLDS>
+__global__ void __launch_bounds__(128) k_rollout_car_duo(RolloutArgs a) {
+    const int b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // 0: dynamics, 1: reward
+    const int k = blockIdx.x * 64 + lane;
+    const int K = a.K, T = a.T;
+    const bool valid = k < K;
+    const int kk = valid ? k : K - 1;
+    constexpr int as = 2;
+    const CarParams& p = a.env.car;
+    extern __shared__ __attribute__((aligned(16))) double sh_dyn[];
+    __shared__ double sh_state[2][4][64];
+    __shared__ double sh_cc[64];
+    __shared__ int sh_ready, sh_done;                                          // model steps published by wave 0 / consumed by wave 1
+    const Track tk = stage_track<TLDS>(a.env.track, sh_dyn, threadIdx.x, 128);
+    if (threadIdx.x == 0) { sh_ready = 0; sh_done = 0; }
+    __syncthreads();
+    if (role == 0) {
+        CarState s;
+        {
+            const double* xe = a.x0ext + (size_t)b * kCarExt;
+            s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
+            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+        }
+        const double* Eb = a.E + (size_t)b * a.cs * K + kk;
+        const double* Ub = a.Ucur + (size_t)b * a.cs;
+        const double* Uo = a.Uorig + (size_t)b * a.cs;
+        const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs : nullptr;
+        const double lo0 = a.env.lo[0], hi0 = a.env.hi[0], lo1 = a.env.lo[1], hi1 = a.env.hi[1];
+        double cc = 0.0;
+        double e0 = Eb[0], e1 = Eb[K], u0 = Ub[0], u1 = Ub[1];
+        for (int t = 0; t < T; ++t) {
+            const double v0 = u0 + e0, v1 = u1 + e1;                           // V = pol.U + E[:,k]  :271
+            if (t + 1 < T) {
+                e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
+                u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
+            }
+            if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+            const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1);
+            car_action_step<false>(p, s, a0, a1, (t & 3) == 0);
+            const int slot = t & 1;
+            if (t >= 2) while (__hip_atomic_load(&sh_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t - 1) __builtin_amdgcn_s_sleep(1);   // slot free again?
+            sh_state[slot][0][lane] = s.x; sh_state[slot][1][lane] = s.y; sh_state[slot][2][lane] = s.Vx; sh_state[slot][3][lane] = s.Vy;
+            __hip_atomic_store(&sh_ready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        sh_cc[lane] = cc;
+        __hip_atomic_store(&sh_ready, T + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    double cost = 0.0;
+    int near = -1;
+    for (int t = 0; t < T; ++t) {
+        while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+        const int slot = t & 1;
+        const double x = sh_state[slot][0][lane], y = sh_state[slot][1][lane], Vx = sh_state[slot][2][lane], Vy = sh_state[slot][3][lane];
+        __hip_atomic_store(&sh_done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);       // (release: the reads above are complete)
+        const double rew = car_reward(p, tk, x, y, Vx, Vy, &near);
+        cost -= rew;                                                           // utils.jl:138
+    }
+    while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < T + 1) __builtin_amdgcn_s_sleep(1);
+    cost += sh_cc[lane];
+    const double total = cost;
+    if (valid) a.cost[(size_t)b * K + k] = total;
+    if (a.cmin) {
+        unsigned long long key = valid ? cost_key(total) : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
+        if (lane == 0) atomicMin(&a.cmin[b], key);
+        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
+    }
+}
+
 // NC >= 2 cars (MultiCarRacingEnv): lane = c * S + j with S = 64 / NC samples per wave, so every car of a sample lives in the same wave.
 // Per-lane (not wave-uniform) here: the start state, the nominal control U (vector loads, one step ahead like E) and the action bounds
 // (LDS table).  The pairwise reward terms (multi-car_racing.jl:145-158) read the other cars' (x, y) by lane shuffles; the sample's cost is
@@ -317,7 +399,16 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
         if (wide) MPOPIS_LAUNCH_CARS_W(NC, 3, 4, gw, 256); else MPOPIS_LAUNCH_CARS_W(NC, 3, 1, gn, 64);           \
     } while (0)
     switch (a.env.ncars) {
-        case 1: if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64); break;
+        case 1: {
+            // up to 1.5 rollout waves per SIMD (measured crossover: C5 shapes win to 24 trials, lose at 32; the duo kernel fits 3 waves/SIMD):
+            // dynamics and reward in two waves per 64 samples (k_rollout_car_duo); MPOPIS_ROLLOUT_DUO=0: never
+            static const int env_duo = [] { const char* e = getenv("MPOPIS_ROLLOUT_DUO"); return e ? atoi(e) : -1; }();   // = max rollout waves for the duo kernel
+            const long long waves = (long long)a.B * ((a.K + 63) / 64);
+            if (!a.traj && waves <= (env_duo >= 0 ? env_duo : 6 * coop_max_workgroups())) {
+                if (tl) MPOPIS_LAUNCH_K((k_rollout_car_duo<true>), g1, 128); else MPOPIS_LAUNCH_K((k_rollout_car_duo<false>), g1, 128);
+            } else if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64);
+            break;
+        }
         case 2: MPOPIS_LAUNCH_CARS(2); break;
         case 3: MPOPIS_LAUNCH_CARS(3); break;
         case 4: MPOPIS_LAUNCH_CARS(4); break;
