@@ -195,6 +195,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
     h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));   // ~2-4 workgroups per CU in the scatter kernel
+    if (const char* e = getenv("MPOPIS_KSPLIT")) h->ksplit = std::max(1, std::min(32, atoi(e)));
     rc |= dalloc(h, &h->d_part, wcov_mfma_workspace_doubles(B, cs, h->ksplit));
     {
         static const int env_fold = [] { const char* e = getenv("MPOPIS_FOLD_WEIGHTS"); return e ? atoi(e) : 1; }();      // 0: keep the separate reweighting launch (A/B)

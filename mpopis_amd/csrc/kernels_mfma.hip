@@ -8,6 +8,7 @@
 // Fragment layout (f64 16x16x4): A lane l = A[i=l&15][k=l>>4]; B lane l = B[k=l>>4][j=l&15];
 // D lane l, reg r = D[row=(l>>4)+4r][col=l&15].
 #include "engine.h"
+#include <type_traits>
 #include "philox.h"
 
 namespace mpopis {
@@ -172,8 +173,35 @@ __device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q
 
 // SQ = true stages ((x - μ) * rscale[row])^2 instead of (x - μ): the fourth-moment scatter Σ_k z_a² z_b² needed by the
 // Schäfer-Strimmer shrinkage intensity (CE's Σ_est = :ss).
-template <int KC, bool SQ>
-__global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
+// ROWS (cs + ones row in 97..112 => exactly 7 row tiles, KC = 64: every 1-car H = 50 configuration): the 28 tile pairs are dealt to the waves
+// as whole tile ROWS of the lower triangle -- wave w owns rows R1 = 3 + w and R2 = 2 - w (7 pairs each) -- so a wave reads tiles 0..R1 once per
+// k-step and feeds all its MFMAs from them (4..7 operand tiles instead of 14), and a chunk is stored k-permuted, column k of a row at
+// (k & 3) kRowsQ + (k >> 2), so the operands of two consecutive k-steps are one 16-byte ds_read_b128.  Row stride 76 / quarter stride 18 doubles:
+// conflict-free in the four 16-lane groups a b128 read is serviced in (MI355X_MICROARCH.md, LDS table).  LDS read time per chunk drops ~5x; it
+// // is a fifth of the pair-list form's (224 ds_read_b64 per wave and chunk beside 112 MFMAs).  The K range is cut differently into partials (two
+// per workgroup, interleaved by k-step group), so Σ' agrees with the pair-list form to rounding (1e-16 relative), not bit for bit.
+constexpr int kRowsS = 76, kRowsQ = 18;
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+template <int R1, int R2, class Side>
+__device__ __forceinline__ void wcov_rows_chunk(const double* __restrict__ xl, v4f64 (&acc)[kPairsPerWave], Side&& side) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                               // (xl points at this wave's half of the chunk: k-steps 8 half .. 8 half + 7)
+        side(j);                                                // a quarter of this thread's share of the next chunk's staging, issued in the shadow of these 14 MFMAs
+        v2f64 x[R1 + 1];
+#pragma unroll
+        for (int t = 0; t <= R1; ++t) x[t] = *reinterpret_cast<const v2f64*>(xl + t * 16 * kRowsS + 2 * j);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int tb = 0; tb <= R1; ++tb) acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[R1][h], x[tb][h], acc[tb], 0, 0, 0);
+#pragma unroll
+            for (int tb = 0; tb <= R2; ++tb) acc[R1 + 1 + tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[R2 < 0 ? 0 : R2][h], x[tb][h], acc[R1 + 1 + tb], 0, 0, 0);
+        }
+    }
+}
+
+template <int KC, bool SQ, bool ROWS = false>
+__global__ void __launch_bounds__(ROWS ? 512 : 256, ROWS ? 1 : 2) k_wcov_mfma_partial(const double* __restrict__ X, const double* __restrict__ w, const int32_t* __restrict__ idx,
                                                            const double* __restrict__ mu, const double* __restrict__ rscale,
                                                            double* __restrict__ part, int cs, int K, int m,
                                                            int ksplit, int npairs, const int* active, int aug,
@@ -184,9 +212,11 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const int nt = (cs + 15) / 16, rows_pad = nt * 16;
-    constexpr int S = KC + 1;                                   // LDS row stride (doubles); odd strides measured best (tools/kbench)
-    constexpr int kMaxLd = (KC == 64) ? 28 : 32;                // staged elements per thread and chunk (cs <= 112 resp. 512 rows)
-    constexpr int kRowStep = 256 / KC;
+    static_assert(!ROWS || (KC == 64 && !SQ), "row form: 64-column chunks, plain scatter");
+    constexpr int S = ROWS ? kRowsS : KC + 1;                   // LDS row stride (doubles); pair-list form: odd strides measured best (tools/kbench)
+    constexpr int NTHR = ROWS ? 512 : 256;
+    constexpr int kMaxLd = ROWS ? 14 : (KC == 64) ? 28 : 32;    // staged elements per thread and chunk (cs <= 112 resp. 512 rows)
+    constexpr int kRowStep = NTHR / KC;
     double* Xs = smem;                                          // [rows_pad][S]
     double* ws = smem + (size_t)rows_pad * S;                   // [KC]
     double* wsl = ws + KC;                                      // [per] (weights-from-costs form) the k range's unnormalised weights
@@ -199,13 +229,17 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     const int qbase = blockIdx.y * kPairsPerBlock + wv * kPairsPerWave;
 #pragma unroll
     for (int p = 0; p < kPairsPerWave; ++p) {
-        if (qbase + p < npairs) decode_pair(qbase + p, &pa[p], &pb[p]); else { pa[p] = 0; pb[p] = 0; }   // dummy tile, result dropped
+        if (ROWS) { const int r1 = 3 + (wv & 3), r2 = 2 - (wv & 3); pa[p] = (p <= r1) ? r1 : r2; pb[p] = (p <= r1) ? p : p - r1 - 1; }
+        else if (qbase + p < npairs) decode_pair(qbase + p, &pa[p], &pb[p]); else { pa[p] = 0; pb[p] = 0; }   // dummy tile, result dropped
     }
     v4f64 acc[kPairsPerWave];
 #pragma unroll
     for (int p = 0; p < kPairsPerWave; ++p) acc[p] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int per = ((m + ksplit - 1) / ksplit + KC - 1) / KC * KC;          // k range per split, multiple of KC
-    const int kbeg = blockIdx.x * per, kend = min(m, kbeg + per);
+    // (row form: a workgroup of 8 waves covers TWO splits' worth of columns; waves 0-3 / 4-7 take the first / second four k-step pairs of every
+    //  chunk and write partial 2 blockIdx.x + half -- two MFMA streams per SIMD, one LDS image pair)
+    const int wgper = ROWS ? 2 * per : per;
+    const int kbeg = blockIdx.x * wgper, kend = min(m, kbeg + wgper);
     // staging map: this thread always handles column kk of a chunk and rows r0 + u*kRowStep
     const int skk = threadIdx.x % KC, sr0 = threadIdx.x / KC;
     // !SQ: rows are staged UNcentred and the finish kernel subtracts μ μ' Σw (Σ w (x-μ)(x-μ)' = Σ w x x' - μ μ' Σw for
@@ -225,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
         // are still free.
         const double rho = cost_unkey(cminp[b]);
         // (stored as sqrt(w_k) = exp(-1/(2λ) (c_k - ρ)): the rows are staged as sqrt(w_k) x_k, see below)
-        for (int kq = kbeg + (int)threadIdx.x; kq < kend; kq += 256) wsl[kq - kbeg] = exp(0.5 * neg_inv_lambda * (costp[(size_t)b * K + kq] - rho));
+        for (int kq = kbeg + (int)threadIdx.x; kq < kend; kq += NTHR) wsl[kq - kbeg] = exp(0.5 * neg_inv_lambda * (costp[(size_t)b * K + kq] - rho));
         __syncthreads();
     }
     bool kin_cur = false;
@@ -241,12 +275,25 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
     const double* pA[kPairsPerWave]; const double* pB[kPairsPerWave];
 #pragma unroll
     for (int p = 0; p < kPairsPerWave; ++p) { pA[p] = Xs + (size_t)(pa[p] * 16 + li) * S + lk; pB[p] = Xs + (size_t)(pb[p] * 16 + li) * S + lk; }
-    if (kbeg < kend) load_chunk(kbeg);
-    for (int c0 = kbeg; c0 < kend; c0 += KC) {
+    // Rows are staged as sqrt(w_k) x_k: Σ_k w_k x_a x_b = Σ_k (sqrt(w_k) x_a)(sqrt(w_k) x_b), so the weight costs one multiply per staged
+    // element (28 per thread and chunk) instead of one per MFMA operand (112 per lane and chunk, on the datapath the MFMAs share).
+    auto stage_chunk = [&](double* dst, int c0) {               // the chunk held in xreg / wreg -> LDS
         kin_cur = (c0 + skk) < kend;
-        // Rows are staged as sqrt(w_k) x_k: Σ_k w_k x_a x_b = Σ_k (sqrt(w_k) x_a)(sqrt(w_k) x_b), so the weight costs one multiply per staged
-        // element (28 per thread and chunk) instead of one per MFMA operand (112 per lane and chunk, on the datapath the MFMAs share).
         const double sw = weighted ? wreg : 1.0;
+        if (ROWS) {
+            // straight-line form: 7 row tiles = 28 rows per thread exactly (no store guard), rows below 96 are data rows whatever cs in 97..112 is,
+            // and a column beyond the k range is zeroed through its weight
+            const double swk = kin_cur ? sw : 0.0;
+            double* d0 = dst + (size_t)sr0 * S + ((skk & 3) * kRowsQ + (skk >> 2));
+#pragma unroll
+            for (int u = 0; u < kMaxLd; ++u) {
+                const int row = sr0 + u * kRowStep;
+                double v = weighted ? xreg[u] * swk : (kin_cur ? xreg[u] : 0.0);
+                if (u * kRowStep + kRowStep > 96) v = (row < cs) ? v : ((aug && row == cs) ? swk : 0.0);
+                d0[(size_t)u * kRowStep * S] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kMaxLd; ++u) {
             const int row = sr0 + u * kRowStep;
@@ -255,22 +302,77 @@ __global__ void __launch_bounds__(256, 2) k_wcov_mfma_partial(const double* __re
             if (weighted) v *= sw;
             // zero padded; aug: the first padding row carries ones (times sqrt(w_k)), so row cs of the scatter is Σ_k w_k x_k (the weighted
             // mean comes out of the same pass over X and the separate E·w kernel is not needed) and its diagonal entry is Σ_k w_k
-            if (row < rows_pad) Xs[(size_t)row * S + skk] = (kin_cur && row < cs) ? v : ((aug && row == cs && kin_cur) ? sw : 0.0);
+            const int pos = ROWS ? (skk & 3) * kRowsQ + (skk >> 2) : skk;
+            if (row < rows_pad) dst[(size_t)row * S + pos] = (kin_cur && row < cs) ? v : ((aug && row == cs && kin_cur) ? sw : 0.0);
         }
+    };
+    if (kbeg < kend) load_chunk(kbeg);
+    if (ROWS) {
+        // two LDS images, one barrier per chunk, one workgroup per CU: a wave writes chunk c+1 (loaded during chunk c-1) into the other image and
+        // issues the loads of chunk c+2, then runs the 112 MFMAs of chunk c -- nothing between two MFMA phases but those ~90 issue slots, where the
+        // single-image form had two barriers and the whole staging pass (the matrix pipe idled ~45 % of the kernel)
+        double* Xs1 = wsl + (costp ? wgper : 0);
+        if (kbeg < kend) { stage_chunk(Xs, kbeg); load_chunk(kbeg + KC); }      // (clamped addresses: a chunk beyond the range loads valid memory)
         __syncthreads();
-        if (c0 + KC < kend) load_chunk(c0 + KC);                // next chunk's loads fly during the MFMAs
+        // (the loop is instantiated once per wave role, so the accumulators stay in their registers across chunks)
+        auto run = [&](auto r1c, auto r2c) {
+        int it = 0;
+        for (int c0 = kbeg; c0 < kend; c0 += KC, ++it) {
+            double* cur = (it & 1) ? Xs1 : Xs;
+            double* nxt = (it & 1) ? Xs : Xs1;
+            // chunk c+1 sits in xreg / wreg: it is written to the other image, and chunk c+2 loaded into the freed registers, four rows at a time
+            // between the MFMA groups of chunk c (straight-line; for the last chunks this stages zeros / loads clamped addresses that nobody reads)
+            const bool kin1 = (c0 + KC + skk) < kend;
+            const double swk = kin1 ? (weighted ? wreg : 1.0) : 0.0;
+            const int kq2 = min(c0 + 2 * KC + skk, kend - 1), col2 = ib ? ib[kq2] : kq2;
+            const double wreg2 = costp ? wsl[kq2 - kbeg] : (wb ? sqrt(wb[col2]) : 1.0);
+            double* d0 = nxt + (size_t)sr0 * S + ((skk & 3) * kRowsQ + (skk >> 2));
+            const double* g0 = Xb + col2;
+            auto side = [&](int j) {
 #pragma unroll
-        for (int kk0 = 0; kk0 < KC; kk0 += 4) {
-#pragma unroll
-            for (int p = 0; p < kPairsPerWave; ++p)             // sqrt(w_k) x_a  x  sqrt(w_k) x_b
-                acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[p][kk0], pB[p][kk0], acc[p], 0, 0, 0);
+                for (int uu = 0; uu < 4; ++uu) {
+                    const int u = 4 * j + uu;
+                    if (u < kMaxLd) {
+                        const int row = sr0 + u * kRowStep;
+                        double v = weighted ? xreg[u] * swk : (kin1 ? xreg[u] : 0.0);
+                        if (u * kRowStep + kRowStep > 96) v = (row < cs) ? v : ((aug && row == cs) ? swk : 0.0);
+                        d0[(size_t)u * kRowStep * S] = v;
+                        xreg[u] = g0[(size_t)min(row, cs - 1) * K];
+                    }
+                }
+            };
+            const double* xl = cur + (size_t)li * S + lk * kRowsQ + 8 * (wv >> 2);
+            wcov_rows_chunk<decltype(r1c)::value, decltype(r2c)::value>(xl, acc, side);
+            wreg = wreg2;
+            __syncthreads();
         }
-        __syncthreads();
+        };
+        switch (wv & 3) {
+            case 0: run(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}); break;
+            case 1: run(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 5>{}, std::integral_constant<int, 0>{}); break;
+            default: run(std::integral_constant<int, 6>{}, std::integral_constant<int, -1>{}); break;
+        }
+    } else {
+        for (int c0 = kbeg; c0 < kend; c0 += KC) {
+            stage_chunk(Xs, c0);
+            __syncthreads();
+            if (c0 + KC < kend) load_chunk(c0 + KC);            // next chunk's loads fly during the MFMAs
+#pragma unroll
+            for (int kk0 = 0; kk0 < KC; kk0 += 4) {
+#pragma unroll
+                for (int p = 0; p < kPairsPerWave; ++p)         // sqrt(w_k) x_a  x  sqrt(w_k) x_b
+                    acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(pA[p][kk0], pB[p][kk0], acc[p], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int p = 0; p < kPairsPerWave; ++p) {
-        if (qbase + p < npairs) {
-            double* pp = part + (((size_t)b * ksplit + blockIdx.x) * npairs + (qbase + p)) * 256 + lane * 4;
+        const int q = ROWS ? pa[p] * (pa[p] + 1) / 2 + pb[p] : qbase + p;
+        if (q < npairs) {
+            const int split = ROWS ? 2 * blockIdx.x + (wv >> 2) : blockIdx.x;
+            double* pp = part + (((size_t)b * ksplit + split) * npairs + q) * 256 + lane * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pp[r] = acc[p][r];
         }
@@ -471,8 +573,13 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     const int nt = (cs + 15) / 16, npairs = nt * (nt + 1) / 2;
     const int kc = wcov_kc(cs);
     const int per = ((m + ksplit - 1) / ksplit + kc - 1) / kc * kc;
-    const size_t lds = ((size_t)nt * 16 * (kc + 1) + kc + (from_cost ? per : 0)) * sizeof(double);
-    static std::atomic<unsigned long long> seen[4];
+    static const int env_rows = [] { const char* e = getenv("MPOPIS_WCOV_ROWS"); return e ? atoi(e) : 1; }();
+    // row form: 7 row tiles (kc == 64 then), an even number of partials, and enough 8-wave workgroups for most of the CUs (measured: wins from 16
+    // resident C5 trials up -- 30 -> 28 us at 16, 86 -> 74 us at 64 -- and loses ~5 us at 8, where it fields 128 workgroups)
+    const bool rows = env_rows && nt == 7 && !rscale && !(ksplit & 1) && (long long)B * (ksplit / 2) >= (env_rows > 1 ? 1 : 192);
+    const size_t lds = ((size_t)nt * 16 * (rows ? 2 * kRowsS : kc + 1) + kc + (from_cost ? (rows ? 2 * per : per) : 0)) * sizeof(double);
+    static std::atomic<unsigned long long> seen[5];
+    ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, false, true>, 160 * 1024, seen[4]);
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, false>, 96 * 1024, seen[0]);
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<16, false>, 96 * 1024, seen[1]);
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, true>, 96 * 1024, seen[2]);
@@ -482,7 +589,8 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
         if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, true>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
     } else {
-        if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
+        if (rows)          hipLaunchKernelGGL((k_wcov_mfma_partial<64, false, true>), dim3(ksplit / 2, 1, B), dim3(512), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
+        else if (kc == 64) hipLaunchKernelGGL((k_wcov_mfma_partial<64, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
         else          hipLaunchKernelGGL((k_wcov_mfma_partial<16, false>), grid, dim3(256), lds, s, X, w, idx, mu, rscale, part, cs, K, m, ksplit, npairs, active, aug, cost, cmin, neg_inv_lambda);
     }
     hipLaunchKernelGGL(k_wcov_mfma_finish, dim3(npairs, B), dim3(256), 0, s, part, w, S, cs, K, ksplit, npairs, den, ridge, active,
