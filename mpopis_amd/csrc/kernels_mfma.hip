@@ -177,8 +177,11 @@ __device__ __forceinline__ void decode_pair(int q, int* ta, int* tb) {      // q
 // as whole tile ROWS of the lower triangle -- wave w owns rows R1 = 3 + w and R2 = 2 - w (7 pairs each) -- so a wave reads tiles 0..R1 once per
 // k-step and feeds all its MFMAs from them (4..7 operand tiles instead of 14), and a chunk is stored k-permuted, column k of a row at
 // (k & 3) kRowsQ + (k >> 2), so the operands of two consecutive k-steps are one 16-byte ds_read_b128.  Row stride 76 / quarter stride 18 doubles:
-// conflict-free in the four 16-lane groups a b128 read is serviced in (MI355X_MICROARCH.md, LDS table).  LDS read time per chunk drops ~5x; it
-// // is a fifth of the pair-list form's (224 ds_read_b64 per wave and chunk beside 112 MFMAs).  The K range is cut differently into partials (two
+// conflict-free in the four 16-lane groups a b128 read is serviced in (MI355X_MICROARCH.md, LDS table).  LDS read time per chunk
+// is a fifth of the pair-list form's (224 ds_read_b64 per wave and chunk beside 112 MFMAs).  What bought the time, measured step by step at 64
+// trials: rows + b128 alone 86 -> 86 us; + two images / one barrier, staging straight-line 86 -> 84; + staging and the next loads issued between
+// the MFMA groups 77; + accumulators resident across chunks 75; + 8 waves (two MFMA streams per SIMD) 74 -- the pair-list form idled the matrix
+// pipe through its staging pass and two barriers per chunk, LDS bandwidth was never the limit.  The K range is cut differently into partials (two
 // per workgroup, interleaved by k-step group), so Σ' agrees with the pair-list form to rounding (1e-16 relative), not bit for bit.
 constexpr int kRowsS = 76, kRowsQ = 18;
 typedef double v2f64 __attribute__((ext_vector_type(2)));
