@@ -27,8 +27,7 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 // L is lower triangular (the sampler's E = L*Z): row tiles above a chunk's block row are skipped.
 // RNG = true: Z is never materialised -- every wave draws the 16 x 16 block of standard normals it needs for the
 //              current chunk from the Philox streams (same counters as k_sample_normal_pair, i.e. the same numbers), two
-//              Box-Muller pairs per lane, and redistributes them into the MFMA B-operand pattern with wave shuffles; the
-//              VALU work of the sampler overlaps the matrix-core work.  Needs n even and all rows in one pass (n <= 128).
+//              Box-Muller pairs per lane (one Philox call), in the MFMA B-operand pattern.  Needs 4 | n and all rows in one pass (n <= 128).
 // oscale2 (nullable, [B]): E = sqrt(oscale2[b]) L Z -- :cmamppi draws from MvNormal(σ²Σ′) (:550-554) and keeps the factor of Σ′ itself: chol(σ²Σ′) = σ chol(Σ′),
 // so the step size only scales the output and the factorisation does not have to wait for it
 struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; const double* panel; size_t pstride; const double* oscale2; };
@@ -63,17 +62,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     double lreg[8], bz[4];
     const uint64_t seed = RNG ? rng.seeds[b] : 0;
     // MFMA slot (q, lk) of a chunk carries column j0 + 4*lk + q of L (and row j0 + 4*lk + q of Z): a lane's four B operands are
-    // then two ADJACENT row pairs of one sample = exactly two Philox / Box-Muller pairs, drawn by the lane that consumes them
+    // then four ADJACENT rows of one sample = the four normals of one Philox call (philox.h), drawn by the lane that consumes them
     // (no cross-lane redistribution).  The LDS panel stores column c in row (c & 3) * 4 + (c >> 2), so that the A-operand
     // reads keep their conflict-free pattern Ls[4q + lk][..].
     auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4lk+q of the stream
+        // (rows beyond n draw from counters past the sample's range; their operands are zeroed below)
         const int kk = min(k0 + li, K - 1);
-#pragma unroll
-        for (int rho = 0; rho < 2; ++rho) {
-            const int row = j0 + 4 * lk + 2 * rho;
-            const uint64_t lin = (uint64_t)kk * n + min(row, n - 2);
-            philox_normal_pair(seed, rng.slo, rng.shi, lin >> 1, sh_tab, &bz[2 * rho], &bz[2 * rho + 1]);
-        }
+        philox_normal_quad(seed, rng.slo, rng.shi, ((uint64_t)kk * n + j0 + 4 * lk) >> 2, sh_tab, bz);             // (4 | n: sample_trmm_fusable)
     };
     // RNG: L comes as the pre-arranged, zero-filled panel copy the Cholesky kernel wrote (k_potrf_lds, Lpanel): row p of chunk c is LDS row p,
     // so staging is 8 plain loads + 8 plain LDS stores per thread and chunk (the generic path spends ~10 VALU per element on clamps,
@@ -148,7 +143,7 @@ void launch_trmm_LZ_mfma(const double* L, size_t Lstride, const double* Z, doubl
                        RngArgs{nullptr, 0, 0, nullptr, nullptr, 0, oscale2}, tpg);
 }
 // E = L * randn(n, K) with the normals drawn inside the kernel (no Z buffer); returns false if the shape needs the 2-kernel path
-bool sample_trmm_fusable(int n) { return !(n & 1) && (n + 15) / 16 <= kTrmmTiles; }
+bool sample_trmm_fusable(int n) { return !(n & 3) && (n + 15) / 16 <= kTrmmTiles; }     // (a lane's four rows = one Philox call)
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2) {
     if (!sample_trmm_fusable(n) || !panel) return false;

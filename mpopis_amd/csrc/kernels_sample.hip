@@ -3,8 +3,8 @@
 //   src/mppi_mpopi_policies.jl:308,359,448,556,657,724,797; rand(rng,P,K,T) at :193 for :mppi)
 // The reference stream (Julia MersenneTwister + ziggurat) is not reproduced; the engine draws from
 // Philox4x32-10 counter streams + Box-Muller (bit-identical to the oracle's generator up to the
-// last-ulp differences of log/sin/cos) or consumes injected normals.  Counter = normal-pair index
-// of the reference's linear draw order; key = per-trial seed; stream = (mpc step, AIS iteration).
+// last-ulp differences of log/sin/cos) or consumes injected normals.  Counter = (index in the reference's
+// linear draw order) / 4 -- four normals per call, philox.h; key = per-trial seed; stream = (mpc step, AIS iteration).
 #include "engine.h"
 #include "philox.h"
 
@@ -70,10 +70,29 @@ __global__ void __launch_bounds__(256) k_sample_normal_pair(double* __restrict__
     Z[((size_t)b * cs + r + 1) * K + k] = z1;
 }
 
+// Quad version (G order, 4 | cs): rows 4 rq .. 4 rq + 3 of sample k are the four normals of one Philox call
+__global__ void __launch_bounds__(256) k_sample_normal_quad(double* __restrict__ Z, int cs, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
+                                                            const double* dscale, const int* active, const double* __restrict__ rng_tab) {
+    const int b = blockIdx.z;
+    if (active && !active[b]) return;
+    __shared__ double sh_tab[kRngTabDoubles];
+    stage_rng_tab(sh_tab, rng_tab, threadIdx.x, 256);
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r = 4 * blockIdx.y;
+    if (k >= K) return;
+    double z[4];
+    philox_normal_quad(seeds[b], slo, shi, ((uint64_t)k * cs + r) >> 2, sh_tab, z);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Z[((size_t)b * cs + r + i) * K + k] = dscale ? z[i] * dscale[(size_t)b * cs + r + i] : z[i];
+}
+
 void launch_sample_normal(double* Z, int B, int cs, int K, int as, int mppi_order, const uint64_t* seeds,
                           uint32_t slo, uint32_t shi, const double* dscale, const int* active, hipStream_t s, const double* rng_tab) {
     const bool pairable = mppi_order ? (as % 2 == 0) : (cs % 2 == 0);
-    if (pairable)
+    if (!mppi_order && cs % 4 == 0)
+        hipLaunchKernelGGL(k_sample_normal_quad, dim3((K + 255) / 256, cs / 4, B), dim3(256), 0, s, Z, cs, K, seeds, slo, shi, dscale, active, rng_tab);
+    else if (pairable)
         hipLaunchKernelGGL(k_sample_normal_pair, dim3((K + 255) / 256, cs / 2, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active, rng_tab);
     else
         hipLaunchKernelGGL(k_sample_normal, dim3((K + 255) / 256, cs, B), dim3(256), 0, s, Z, cs, K, as, mppi_order, seeds, slo, shi, dscale, active, rng_tab);

@@ -44,12 +44,11 @@ __device__ __forceinline__ double log_unit(double u, const double* __restrict__ 
     return fma((double)k, 6.93147180559945286227e-01, logc) + lp;
 }
 
-// (sin, cos)(2 pi u) for u = ((hi:lo) >> 11 + 0.5) 2^-53 straight from the two Philox words: sector j = top 6 bits, x = 2 pi (frac - 0.5)/64
-// (exact), degree-7 / degree-8 Taylor kernels on |x| <= 0.0491 and one rotation by the tabulated sector centre.
-__device__ __forceinline__ void sincos_2pi_bits(uint32_t hi, uint32_t lo, const double* __restrict__ tab, double* sn, double* cs) {
-    const int j = hi >> 26;
-    const double fh = (double)(hi & 0x3ffffffu), fl = (double)(lo >> 11);
-    const double f = fma(fh, 0x1p-26, fma(fl, 0x1p-47, 0x1p-48 - 0.5));          // 64 u - j - 0.5, exact
+// (sin, cos)(2 pi u) for u = (w + 0.5) 2^-32 straight from one Philox word: sector j = top 6 bits, x = 2 pi (frac - 0.5)/64 (exact), degree-7 /
+// degree-8 Taylor kernels on |x| <= 0.0491 and one rotation by the tabulated sector centre.
+__device__ __forceinline__ void sincos_2pi_u32(uint32_t w, const double* __restrict__ tab, double* sn, double* cs) {
+    const int j = w >> 26;
+    const double f = fma((double)(w & 0x3ffffffu), 0x1p-26, 0x1p-27 - 0.5);      // 64 u - j - 0.5, exact
     const double x = f * 9.81747704246810387019e-02, z = x * x;                  // 2 pi / 64
     double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
     ps = fma(z, ps, -1.0 / 6.0);
@@ -63,13 +62,16 @@ __device__ __forceinline__ void sincos_2pi_bits(uint32_t hi, uint32_t lo, const 
     *cs = fma(C, c, -(S * s));
 }
 
-__device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, const double* __restrict__ tab, double* z0, double* z1) {
-    uint32_t r[4];
-    philox4x32_10((uint32_t)j, (uint32_t)(j >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-    // u = ((a >> 11) + 0.5) 2^-53 for the 64-bit word a = (hi:lo), one rounding: (a >> 11) = hi 2^21 + (lo >> 11), so
-    // u = hi 2^-32 + ((lo >> 11) + 0.5) 2^-53 with both conversions exact -- two v_cvt_f64_u32 and two fmas per uniform
-    // (the largest word, a >> 11 = 2^53 - 1, would round to u1 = 1.0 -> log = 0 -> rsq(0) = inf -> NaN normals: keep u1 < 1)
-    const double u1 = fmin(fma((double)r[1], 0x1p-32, fma((double)(r[0] >> 11), 0x1p-53, 0x1p-54)), 1.0 - 0x1p-53);
+// ---- the normal stream ---------------------------------------------------------------------------------------------------------------------
+// One Philox4x32-10 call (counter = q, stream words, key = seed) yields FOUR standard normals, numbers 4q .. 4q+3 of the stream: Box-Muller on
+// (w0, w1) and on (w2, w3), radius word first, with 32-bit uniforms u = (w + 0.5) 2^-32 in (0, 1).  Round 2 spent a whole call on one pair
+// (two 53-bit uniforms); the twenty v_mad_u64_u32 of a call were the largest single item of the fused sampler, whose VALU work does NOT overlap
+// the FP64 MFMAs of its neighbours (tools/mfma_valu_overlap.hip: the two serialise on a SIMD).  What 32 bits cost: the radius sqrt(-2 log u)
+// takes 2^32 values and stops at 6.66 (mass beyond: 2.7e-11 -- one draw in 1400 full C5 steps); neighbouring radii differ by <= 4e-10 relative in
+// the bulk.  The reference's stream (MersenneTwister + ziggurat) is not reproduced either way; oracle/mpopis_oracle.c (orc_philox_normals)
+// defines the same stream with libm.
+__device__ __forceinline__ void box_muller_u32(uint32_t wr, uint32_t wa, const double* __restrict__ tab, double* z0, double* z1) {
+    const double u1 = fma((double)wr, 0x1p-32, 0x1p-33);       // exact, < 1
     // sqrt of a positive normal-range number: v_rsq_f64 seed + coupled Newton step + residual correction (1 ulp, see
     // tools/rcp_acc.hip) instead of the library sqrt with its denormal rescaling (8 instead of 18 VALU ops)
     const double v = -2.0 * log_unit(u1, tab);
@@ -79,10 +81,24 @@ __device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, 
     g = fma(g, rr, g); h = fma(h, rr, h);
     const double R = fma(fma(-g, g, v), h, g);
     double s, c;
-    sincos_2pi_bits(r[3], r[2], tab, &s, &c);                   // = sin/cos(2π u2), u2 = ((r3:r2) >> 11 + 0.5) 2^-53
+    sincos_2pi_u32(wa, tab, &s, &c);
     *z0 = R * c; *z1 = R * s;
 }
-
+// normals 4q .. 4q+3
+__device__ __forceinline__ void philox_normal_quad(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t q, const double* __restrict__ tab, double* z) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    box_muller_u32(r[0], r[1], tab, &z[0], &z[1]);
+    box_muller_u32(r[2], r[3], tab, &z[2], &z[3]);
+}
+// normals 2j, 2j+1 (half a call's output: for consumers that cannot use all four)
+__device__ __forceinline__ void philox_normal_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64_t j, const double* __restrict__ tab, double* z0, double* z1) {
+    uint32_t r[4];
+    const uint64_t q = j >> 1;
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), slo, shi, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const bool hi = j & 1;
+    box_muller_u32(hi ? r[2] : r[0], hi ? r[3] : r[1], tab, z0, z1);
+}
 // the tables live in global memory (one copy per handle, filled by launch_rng_tab_init at creation); kernels stage them into LDS
 __device__ __forceinline__ void stage_rng_tab(double* sh_tab, const double* __restrict__ gtab, int tid, int nthreads) {
     for (int i = tid; i < kRngTabDoubles; i += nthreads) sh_tab[i] = gtab[i];

@@ -461,18 +461,25 @@ static inline void philox_pair(uint64_t seed, uint32_t slo, uint32_t shi, uint64
     *b = ((uint64_t)r[3] << 32) | r[2];
 }
 
+/* The normal stream (the engine's definition, mpopis_amd/csrc/philox.h): call q (counter = q, stream words, key = seed) yields normals
+ * 4q .. 4q+3 -- Box-Muller on (w0, w1) and on (w2, w3), radius word first, uniforms u = (w + 0.5) 2^-32. */
+static inline void box_muller_u32(uint32_t wr, uint32_t wa, double *z0, double *z1) {
+    const double two_m32 = 1.0 / 4294967296.0;
+    double u1 = ((double)wr + 0.5) * two_m32, u2 = ((double)wa + 0.5) * two_m32;
+    double R = sqrt(-2.0 * log(u1));
+    double th = 6.283185307179586476925286766559 * u2;
+    *z0 = R * cos(th); *z1 = R * sin(th);
+}
 void orc_philox_normals(uint64_t seed, uint32_t slo, uint32_t shi, int64_t n, double *out) {
-    const double two_m53 = 1.0 / 9007199254740992.0;
-    for (int64_t j = 0; 2 * j < n; ++j) {
-        uint64_t a, b;
-        philox_pair(seed, slo, shi, (uint64_t)j, &a, &b);
-        double u1 = ((double)(a >> 11) + 0.5) * two_m53;
-        double u2 = ((double)(b >> 11) + 0.5) * two_m53;
-        if (u1 >= 1.0) u1 = 1.0 - two_m53;          /* a >> 11 = 2^53 - 1 rounds to 1.0: keep log(u1) < 0 (same clamp as the device generator) */
-        double R = sqrt(-2.0 * log(u1));
-        double th = 6.283185307179586476925286766559 * u2;
-        out[2 * j] = R * cos(th);
-        if (2 * j + 1 < n) out[2 * j + 1] = R * sin(th);
+    for (int64_t q = 0; 4 * q < n; ++q) {
+        uint32_t ctr[4] = { (uint32_t)q, (uint32_t)((uint64_t)q >> 32), slo, shi };
+        uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+        uint32_t r[4];
+        double z[4];
+        orc_philox4x32_10(ctr, key, r);
+        box_muller_u32(r[0], r[1], &z[0], &z[1]);
+        box_muller_u32(r[2], r[3], &z[2], &z[3]);
+        for (int i = 0; i < 4 && 4 * q + i < n; ++i) out[4 * q + i] = z[i];
     }
 }
 
