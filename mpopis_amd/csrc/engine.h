@@ -83,6 +83,7 @@ struct RolloutArgs {
     int iter_n;
     unsigned long long* cmin;   // nullptr or [B]: running minimum of the slot's costs as an order-preserving key (cost_key), car kernels only
     int* status;                // with cmin: a non-finite cost sets MPOPIS_ERR_ACTION here (what k_weights reports when it runs)
+    int share = 1;              // launches of this size in flight at once (multi-stream schedule): kernel choice goes by the chip's total load
 };
 // order-preserving map double -> uint64 (unsigned comparison == numeric comparison, NaN sorts last) for atomicMin on costs
 __host__ __device__ __forceinline__ unsigned long long cost_key(double v) {

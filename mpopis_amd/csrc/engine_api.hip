@@ -622,6 +622,7 @@ void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const doubl
     a.x0 = d_x; a.x0ext = d_xext; a.t0 = d_t; a.done0 = d_done; a.Ucur = Ucur; a.Uorig = Uorig; a.E = d_E; a.gvec = gvec;
     a.cost = d_cost; a.traj = d_traj; a.active = act; a.iters = iters; a.iter_n = iter_n;
     a.cmin = weights_in_moments ? d_cmin : nullptr; a.status = weights_in_moments ? d_status : nullptr;
+    a.share = coop_share;
     time_begin(0);
     launch_rollout(a, stream);
     time_end();

@@ -403,7 +403,7 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
             // up to 1.5 rollout waves per SIMD (measured crossover: C5 shapes win to 24 trials, lose at 32; the duo kernel fits 3 waves/SIMD):
             // dynamics and reward in two waves per 64 samples (k_rollout_car_duo); MPOPIS_ROLLOUT_DUO=0: never
             static const int env_duo = [] { const char* e = getenv("MPOPIS_ROLLOUT_DUO"); return e ? atoi(e) : -1; }();   // = max rollout waves for the duo kernel
-            const long long waves = (long long)a.B * ((a.K + 63) / 64);
+            const long long waves = (long long)a.B * ((a.K + 63) / 64) * std::max(1, a.share);
             if (!a.traj && waves <= (env_duo >= 0 ? env_duo : 6 * coop_max_workgroups())) {
                 if (tl) MPOPIS_LAUNCH_K((k_rollout_car_duo<true>), g1, 128); else MPOPIS_LAUNCH_K((k_rollout_car_duo<false>), g1, 128);
             } else if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64);
