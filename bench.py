@@ -394,13 +394,14 @@ def main():
         ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
         ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
         m_ms, m_n = tm_multi["rollout"]
-        traffic, valu_busy, flops_exec = None, None, None
+        traffic, valu_busy, flops_exec, valu_per_rollout, clock_ghz = None, None, None, None, None
         pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")      # written by tools/pmc_summary.py from separate --pmc passes
         if os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
                 traffic, valu_busy = pm.get("hbm_bytes_per_rollout") * per_launch, pm.get("valu_busy_frac")
                 flops_exec = pm.get("fp64_flops_per_rollout")
+                valu_per_rollout, clock_ghz = pm.get("valu_insts_per_rollout"), pm.get("effective_clock_ghz")
             except Exception:
                 traffic = None
         srt = sorted(samples)
@@ -431,6 +432,15 @@ def main():
                                           if ms_multi is not None else "not measured (python bench.py --multi-stream; DESIGN.md section 5 has the same-box A/B: 1-3 % faster steps at >= 64 trials)"),
                          "bound_note": "achieved / peak / frac are the HBM figure the bench contract prescribes (contract_bound); `bound` names the resource that actually limits the kernel; valu_busy_frac from the PMC pass in profiles/",
                          "valu_busy_frac": valu_busy,
+                         # what the FP64 VALU sustains: tools/mfma_rate.hip -- bare independent v_fma_f64 streams issue one wave-instruction per
+                         # 5.0 cycles per SIMD at 4 waves per SIMD (the kernel's occupancy: 128 VGPRs), 4.6 at 8, 8.8 from a lone wave; the
+                         # data-sheet rate is 4.0.  attained = (VALU wave-instructions per launch x 5.0 cycles / 1024 SIMDs / clock) / launch time
+                         "issue_rate": ({"valu_wave_insts_per_rollout": valu_per_rollout, "cycles_per_inst_attainable_4_waves": 5.0, "cycles_per_inst_datasheet": 4.0,
+                                         "clock_ghz": clock_ghz,
+                                         "frac_of_attainable": valu_per_rollout * per_launch / 64.0 * 5.0 / 1024.0 / (clock_ghz * 1e9) / r_avg_s,
+                                         "frac_of_datasheet": valu_per_rollout * per_launch / 64.0 * 4.0 / 1024.0 / (clock_ghz * 1e9) / r_avg_s,
+                                         "source": "profiles/pmc_rollout.json (SQ_INSTS_VALU, clock from GRBM_GUI_ACTIVE) + tools/mfma_rate.hip"}
+                                        if valu_per_rollout and clock_ghz else None),
                          "fp64_reference_algorithm_tflops": ach_tf, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
                          "fp64_reference_algorithm_frac": ach_tf / FP64_PEAK_TFLOPS,
                          "note": "fp64_reference_* prices SURVEY 8(d)'s 3.5e5 flop-equivalents of the REFERENCE formulation per rollout; the kernel executes ~4x fewer (transcendental-free sub-step), so this can exceed 1"},

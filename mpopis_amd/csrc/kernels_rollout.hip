@@ -45,9 +45,22 @@ inline size_t track_lds_bytes(int P, int W, bool all) {
 // TLDS: every track table fits the default 64 KB of dynamic LDS (P <= ~230 points: all bundled tracks).  Otherwise only the ring table of the
 // straight-line nearest-point search is staged (40 B per point) and the general search -- first step of a rollout, lanes far off their
 // anchor -- reads the coordinate / neighbour tables from global memory.
+#ifdef MPOPIS_ROLL_PROF
+// dev build (tools/roll_prof.sh): start / end time (s_memrealtime, 100 MHz) and hardware id of every wave of the last 1-car launch.
+// What it showed (C5, 64 trials, 4 waves per SIMD): the waves of a SIMD do not progress together -- issue arbitration is oldest-first, the oldest
+// wave runs at the lone-wave rate and ends at ~146 us, the youngest at ~376 us -- but evening them out with rotating s_setprio levels (per action,
+// by wave slot and clock) narrowed the spread to 259..374 us WITHOUT shortening the launch: the SIMD's throughput is the same either way,
+// ~5.0 cycles per FP64 instruction at 4 waves (tools/mfma_rate.hip measures 5.0 for bare v_fma_f64 streams at 4 waves per SIMD, 4.6 at 8), and
+// 43.0 k instructions x 4 waves x 5.0 cycles = the measured launch.  The kernel is at the attainable issue rate; only fewer instructions help.
+__device__ unsigned long long g_roll_prof[3 * 8192];
+extern "C" int mpopis_debug_roll_prof(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_roll_prof), sizeof(g_roll_prof)); }
+#endif
 template <int NC, int SPB, bool LOG, bool TLDS>
 __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car(RolloutArgs a) {
     static_assert(NC == 1, "multi-car envs run k_rollout_cars");
+#ifdef MPOPIS_ROLL_PROF
+    const unsigned long long prof_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
@@ -112,6 +125,16 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
         if (lane == 0) atomicMin(&a.cmin[b], key);
         if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
     }
+#ifdef MPOPIS_ROLL_PROF
+    if (lane == 0) {
+        const int w = (blockIdx.y * gridDim.x + blockIdx.x) * SPB + wave;
+        if (w < 8192) {
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_roll_prof[3 * w] = prof_t0; g_roll_prof[3 * w + 1] = __builtin_amdgcn_s_memrealtime(); g_roll_prof[3 * w + 2] = ((unsigned long long)xcc << 32) | hwid;
+        }
+    }
+#endif
 }
 
 // One car, few rollouts (the lone-wave regime: fewer waves than SIMDs -- one trial of K <= 4096, or the 8-trials-per-GPU share of a strong-scaled
