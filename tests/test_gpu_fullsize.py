@@ -73,6 +73,35 @@ def test_policy_step_full_size_invariants(eng_mod, oracle, track):
     assert not np.array_equal(outs[0]["cost"][0], outs[0]["cost"][1])        # trials use different seeds
 
 
+def test_bench_batch_agrees_with_small_batches(eng_mod, track):
+    """The bench shape itself -- 64 resident C5 trials, device RNG -- takes kernels the oracle-parity cases (1..4 slots) do not: the four-waves-per-SIMD
+    rollout kernel instead of the two-wave one, the row form of the scatter kernel, 8 instead of 32 K-split partials.  Trials are independent and
+    seeded per slot, so slot b of the 64-slot handle must reproduce the same trial run in a 2-slot handle: costs of the first AIS iteration's samples
+    aside (identical), everything downstream agrees to the rounding of the differently cut partial sums."""
+    K, T, N, B = 4096, 50, 10, 64
+    seeds = 20240000 + 1 + np.arange(B, dtype=np.uint64)
+    big = eng_mod.Engine("car", 1, "musigmaaismppi", K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track)
+    big.seed_slots(seeds)
+    ob = [big.policy_step(None), big.policy_step(None)]
+    Ub, Sb = big.get_U(), big.get_Sigma()
+    big.close()
+    for pair in ((0, 63), (17, 40)):
+        small = eng_mod.Engine("car", 1, "musigmaaismppi", K, T, batch=2, lam=10.0, ais_its=N, lam_ais=20.0, cov=[0.0625, 0.1], track=track)
+        small.seed_slots(seeds[list(pair)])
+        os_ = [small.policy_step(None), small.policy_step(None)]
+        Us, Ss = small.get_U(), small.get_Sigma()
+        small.close()
+        idx = list(pair)
+        for step in range(2):
+            assert np.array_equal(ob[step]["iters_run"][idx], os_[step]["iters_run"])
+            assert np.max(np.abs(ob[step]["control"][idx] - os_[step]["control"])) < 1e-8
+            c1, c2 = ob[step]["cost"][idx], os_[step]["cost"]
+            assert np.max(np.abs(c1 - c2) / np.maximum(1.0, np.abs(c2))) < 1e-7
+            assert np.max(np.abs(ob[step]["weights"][idx] - os_[step]["weights"])) < 1e-7
+        assert np.max(np.abs(Ub[idx] - Us)) < 1e-8
+        assert np.max(np.abs(Sb.reshape(B, -1)[idx] - Ss.reshape(2, -1))) < 1e-9 * np.max(np.abs(Ss))
+
+
 def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
     """Bit-exact resampling indices at K=4096 given identical weights and draws (alias table + sampling)."""
     K = 4096
