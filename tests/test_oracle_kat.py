@@ -23,6 +23,36 @@ def test_philox_normals_moments_and_streams(oracle):
     assert not np.allclose(z[:100], oracle.philox_normals(7, 3, 2, 100))
 
 
+def test_philox_normals_four_per_call(oracle):
+    """The stream's definition (mpopis_amd/csrc/philox.h, orc_philox_normals): call q yields normals 4q .. 4q+3 = Box-Muller on (w0, w1) and on
+    (w2, w3) with 32-bit uniforms (w + 0.5) 2^-32 -- restated here from the Philox words -- and, as a distribution: Kolmogorov-Smirnov against the
+    normal CDF, independence of the four outputs of a call (the two Box-Muller outputs of a pair share their radius: uncorrelated, and so are
+    their squares only through the angle), tails at 3 and 4 sigma at the binomial level, nothing beyond sqrt(-2 log 2^-33) = 6.76."""
+    from scipy import stats
+    n = 1 << 20
+    z = oracle.philox_normals(12345, 2, 5, n)
+    for q in (0, 1, 77, n // 4 - 1):
+        w = oracle.philox4x32_10([q & 0xffffffff, q >> 32, 2, 5], [12345, 0])
+        ref = []
+        for wr, wa in ((w[0], w[1]), (w[2], w[3])):
+            u1, u2 = (wr + 0.5) / 2.0 ** 32, (wa + 0.5) / 2.0 ** 32
+            R = math.sqrt(-2.0 * math.log(u1))
+            ref += [R * math.cos(2 * math.pi * u2), R * math.sin(2 * math.pi * u2)]
+        np.testing.assert_allclose(z[4 * q:4 * q + 4], ref, rtol=0, atol=1e-13)
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    Q = z.reshape(-1, 4)
+    C = np.corrcoef(Q.T)
+    assert np.max(np.abs(C - np.eye(4))) < 5.0 / math.sqrt(Q.shape[0])                      # 5 sigma of a sample correlation
+    C2 = np.corrcoef((Q ** 2).T)
+    assert np.max(np.abs(C2 - np.eye(4))) < 5.0 / math.sqrt(Q.shape[0])
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 5.0 / math.sqrt(n)
+    for thr in (3.0, 4.0):
+        p = 2 * stats.norm.sf(thr)
+        k = int(np.sum(np.abs(z) > thr))
+        assert abs(k - n * p) < 5 * math.sqrt(n * p) + 1
+    assert np.max(np.abs(z)) < 6.76
+
+
 def test_compute_weights_kat(oracle):
     w = oracle.compute_weights(1.0, [1.0, 2.0, 3.0])
     e = np.array([1.0, math.exp(-1), math.exp(-2)])
