@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
 #endif
 }
 
-// One car, few rollouts (the lone-wave regime: fewer waves than SIMDs -- one trial of K <= 4096, or the 8-trials-per-GPU share of a strong-scaled
+// One car, few rollouts (up to two rollout waves per SIMD -- one trial of K <= 4096, or the 8 .. 32-trials-per-GPU share of a strong-scaled
 // run).  A wave alone on a SIMD issues one FP64 instruction per ~8.4 cycles whatever it does, so a rollout costs its instruction count and most
 // of the chip idles.  Here a workgroup is TWO waves for 64 samples: wave 0 integrates the dynamics (V = U + E, clamp, car_action_step) and hands
 // (x, y, Vx, Vy) after every model step to wave 1 through a two-slot LDS mailbox; wave 1 evaluates the reward (nearest-point search, lane test,
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
 // bit-identical costs -- with the dynamics wave's chain 11 % shorter.  The mailbox is release / acquire at workgroup scope; the reward wave is
 // ~8x faster than the dynamics wave, so the producer practically never waits for a free slot.
 template <bool TLDS>
-__global__ void __launch_bounds__(128) k_rollout_car_duo(RolloutArgs a) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car_duo(RolloutArgs a) {
     const int b = blockIdx.y;
     if (a.active && !a.active[b]) return;
     if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
@@ -423,11 +423,12 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     } while (0)
     switch (a.env.ncars) {
         case 1: {
-            // up to 1.5 rollout waves per SIMD (measured crossover: C5 shapes win to 24 trials, lose at 32; the duo kernel fits 3 waves/SIMD):
+            // up to 2 rollout waves per SIMD (measured crossover, C5 shapes: 3.49 vs 3.95 ms at 32 trials, 5.36 vs 4.71 at 48; the duo kernel is held to
+            // 128 VGPRs = 4 waves per SIMD, so two dynamics and two reward waves share a SIMD there):
             // dynamics and reward in two waves per 64 samples (k_rollout_car_duo); MPOPIS_ROLLOUT_DUO=0: never
             static const int env_duo = [] { const char* e = getenv("MPOPIS_ROLLOUT_DUO"); return e ? atoi(e) : -1; }();   // = max rollout waves for the duo kernel
             const long long waves = (long long)a.B * ((a.K + 63) / 64) * std::max(1, a.share);
-            if (!a.traj && waves <= (env_duo >= 0 ? env_duo : 6 * coop_max_workgroups())) {
+            if (!a.traj && waves <= (env_duo >= 0 ? env_duo : 8 * coop_max_workgroups())) {
                 if (tl) MPOPIS_LAUNCH_K((k_rollout_car_duo<true>), g1, 128); else MPOPIS_LAUNCH_K((k_rollout_car_duo<false>), g1, 128);
             } else if (wide) MPOPIS_LAUNCH_CAR(1, 4, g4, 256); else MPOPIS_LAUNCH_CAR(1, 1, g1, 64);
             break;
