@@ -306,6 +306,104 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
     }
 }
 
+// The two-wave form of k_rollout_cars for few rollout waves (k_rollout_car_duo explains why): wave 0 integrates all cars of its S samples, wave 1 takes
+// (x, y, Vx, Vy) of every lane per model step from the LDS mailbox and evaluates the per-car reward AND the pair terms (lane shuffles among
+// its own lanes, as in k_rollout_cars), accumulates the cost and gathers the sample's total over its cars.  Same arithmetic, same order.
+template <int NC, bool TLDS>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))) k_rollout_cars_duo(RolloutArgs a) {
+    static_assert(NC >= 2 && NC <= kMaxCars, "2..4 cars");
+    constexpr int S = 64 / NC;
+    const int b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    if (a.iters && blockIdx.x == 0 && threadIdx.x == 0) a.iters[b] = a.iter_n;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // 0: dynamics, 1: reward
+    const int c = min(lane / S, NC - 1), j = lane - c * S;
+    const int k = blockIdx.x * S + j;
+    const int K = a.K, T = a.T;
+    const bool valid = j < S && k < K;
+    const int kk = min(k, K - 1);
+    constexpr int as = 2 * NC;
+    const CarParams& p = a.env.car;
+    extern __shared__ __attribute__((aligned(16))) double sh_dyn[];
+    __shared__ double sh_bnd[NC][4];
+    __shared__ double sh_state[2][4][64];
+    __shared__ double sh_cc[64];
+    __shared__ int sh_ready, sh_done;
+    const Track tk = stage_track<TLDS>(a.env.track, sh_dyn, threadIdx.x, 128);
+    if (threadIdx.x < NC) {
+        const int q = threadIdx.x;
+        sh_bnd[q][0] = a.env.lo[2 * q]; sh_bnd[q][1] = a.env.hi[2 * q]; sh_bnd[q][2] = a.env.lo[2 * q + 1]; sh_bnd[q][3] = a.env.hi[2 * q + 1];
+    }
+    if (threadIdx.x == 0) { sh_ready = 0; sh_done = 0; }
+    __syncthreads();
+    if (role == 0) {
+        CarState s;
+        {
+            const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
+            s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
+            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+        }
+        const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
+        const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
+        const double* Uo = a.Uorig + (size_t)b * a.cs + 2 * c;
+        const double* gv = a.gvec ? a.gvec + (size_t)b * a.cs + 2 * c : nullptr;
+        double cc = 0.0;
+        double e0 = Eb[0], e1 = Eb[K], u0 = Ub[0], u1 = Ub[1];
+        for (int t = 0; t < T; ++t) {
+            const double v0 = u0 + e0, v1 = u1 + e1;                           // V = pol.U + E[:,k]  :271
+            if (t + 1 < T) {
+                e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
+                u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
+            }
+            if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+            const double a0 = clampd_v(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd_v(v1, sh_bnd[c][2], sh_bnd[c][3]);
+            car_action_step<false>(p, s, a0, a1, (t & 3) == 0);
+            const int slot = t & 1;
+            if (t >= 2) while (__hip_atomic_load(&sh_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t - 1) __builtin_amdgcn_s_sleep(1);
+            sh_state[slot][0][lane] = s.x; sh_state[slot][1][lane] = s.y; sh_state[slot][2][lane] = s.Vx; sh_state[slot][3][lane] = s.Vy;
+            __hip_atomic_store(&sh_ready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        sh_cc[lane] = cc;
+        __hip_atomic_store(&sh_ready, T + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    double cost = 0.0;
+    int near = -1;
+    for (int t = 0; t < T; ++t) {
+        while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+        const int slot = t & 1;
+        const double x = sh_state[slot][0][lane], y = sh_state[slot][1][lane], Vx = sh_state[slot][2][lane], Vy = sh_state[slot][3][lane];
+        __hip_atomic_store(&sh_done, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        double rew = car_reward(p, tk, x, y, Vx, Vy, &near);
+#pragma unroll
+        for (int q = 1; q < NC; ++q) {                                         // multi-car_racing.jl:145-158
+            const double xq = __shfl(x, q * S + j, 64), yq = __shfl(y, q * S + j, 64);
+            if (q > c) {
+                const double dx = xq - x, dy = yq - y;
+                const double dd = fast_sqrt(dx * dx + dy * dy);
+                rew += -dd;
+                if (dd <= 4.0) rew += -11000.0;
+            }
+        }
+        cost -= rew;                                                           // utils.jl:138
+    }
+    while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < T + 1) __builtin_amdgcn_s_sleep(1);
+    cost += sh_cc[lane];
+    double total = cost;
+#pragma unroll
+    for (int q = 1; q < NC; ++q) total += __shfl(cost, q * S + j, 64);
+    const bool writer = valid && c == 0;
+    if (writer) a.cost[(size_t)b * K + k] = total;
+    if (a.cmin) {
+        unsigned long long key = writer ? cost_key(total) : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
+        if (lane == 0) atomicMin(&a.cmin[b], key);
+        if (writer && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
+    }
+}
+
 // MountainCar (ss = 2) and CartPole (ss = 4): scalar action, a handful of flops per step
 template <int SS>
 __global__ void __launch_bounds__(64) k_rollout_simple(RolloutArgs a) {
@@ -419,14 +517,19 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     do {                                                                                                         \
         const int S_ = 64 / NC;                                                                                  \
         const dim3 gw((a.K + 4 * S_ - 1) / (4 * S_), a.B), gn((a.K + S_ - 1) / S_, a.B);                          \
-        if (wide) MPOPIS_LAUNCH_CARS_W(NC, 3, 4, gw, 256); else MPOPIS_LAUNCH_CARS_W(NC, 3, 1, gn, 64);           \
+        const long long waves_ = (long long)a.B * ((a.K + S_ - 1) / S_) * std::max(1, a.share);                  \
+        if (!a.traj && waves_ <= (env_duo >= 0 ? env_duo : kDuoCarsWaves * coop_max_workgroups())) {             \
+            if (tl) MPOPIS_LAUNCH_K((k_rollout_cars_duo<NC, true>), gn, 128); else MPOPIS_LAUNCH_K((k_rollout_cars_duo<NC, false>), gn, 128); \
+        } else if (wide) MPOPIS_LAUNCH_CARS_W(NC, 3, 4, gw, 256); else MPOPIS_LAUNCH_CARS_W(NC, 3, 1, gn, 64);    \
     } while (0)
+    // two-wave kernels: MPOPIS_ROLLOUT_DUO = largest rollout-wave count (all parts of a multi-stream schedule together) that still takes them; 0: never
+    static const int env_duo = [] { const char* e = getenv("MPOPIS_ROLLOUT_DUO"); return e ? atoi(e) : -1; }();
+    constexpr int kDuoCarsWaves = 5;                           // multi-car (3 waves per SIMD): measured, C4 shapes -- 5.53 -> 4.86 ms at one trial, 7.18 -> 6.66 at 6 (1176 waves), 7.49 -> 7.68 at 8
     switch (a.env.ncars) {
         case 1: {
             // up to 2 rollout waves per SIMD (measured crossover, C5 shapes: 3.49 vs 3.95 ms at 32 trials, 5.36 vs 4.71 at 48; the duo kernel is held to
             // 128 VGPRs = 4 waves per SIMD, so two dynamics and two reward waves share a SIMD there):
             // dynamics and reward in two waves per 64 samples (k_rollout_car_duo); MPOPIS_ROLLOUT_DUO=0: never
-            static const int env_duo = [] { const char* e = getenv("MPOPIS_ROLLOUT_DUO"); return e ? atoi(e) : -1; }();   // = max rollout waves for the duo kernel
             const long long waves = (long long)a.B * ((a.K + 63) / 64) * std::max(1, a.share);
             if (!a.traj && waves <= (env_duo >= 0 ? env_duo : 8 * coop_max_workgroups())) {
                 if (tl) MPOPIS_LAUNCH_K((k_rollout_car_duo<true>), g1, 128); else MPOPIS_LAUNCH_K((k_rollout_car_duo<false>), g1, 128);

@@ -1,4 +1,4 @@
-"""Helper process for tests/test_gpu_rollout_duo.py: one-car handles in the few-waves regime, a few policy steps each; prints one JSON line with the
+"""Helper process for tests/test_gpu_rollout_duo.py: one-car and multi-car handles in the few-waves regime, a few policy steps each; prints one JSON line with the
 cost vectors and controls as hex (bit patterns).  MPOPIS_ROLLOUT_DUO is read once per process by the library, hence the subprocess."""
 import json
 import os
@@ -10,9 +10,13 @@ import numpy as np
 from mpopis_amd.engine import Engine
 
 out = {}
-for name, pol, K, B, track in (("gmppi", "gmppi", 1024, 1, None), ("ragged", "cemppi", 150, 3, None), ("mu", "musigmaaismppi", 1000, 2, None), ("bigtrack", "imppi", 200, 2, 960)):
-    kw = dict(batch=B, lam=10.0, ais_its=3, cov=np.array([0.0625, 0.1]), seed=4242)
-    eng = Engine("car", 1, pol, K, 50, **kw)
+for name, pol, K, B, track, ncars in (("gmppi", "gmppi", 1024, 1, None, 1), ("ragged", "cemppi", 150, 3, None, 1), ("mu", "musigmaaismppi", 1000, 2, None, 1),
+                                     ("bigtrack", "imppi", 200, 2, 960, 1), ("cars3", "cmamppi", 700, 2, None, 3), ("cars2", "gmppi", 333, 1, None, 2),
+                                     ("cars4", "musigmaaismppi", 256, 2, None, 4)):
+    kw = dict(batch=B, lam=10.0, ais_its=3, cov=np.tile([0.0625, 0.1], ncars), seed=4242)
+    if pol == "cmamppi":
+        kw.update(elite_threshold=0.8, cma_sigma=0.75)
+    eng = Engine("car", ncars, pol, K, 50, **kw)
     if track:
         th = np.linspace(0, 2 * np.pi, track, endpoint=False)
         r = 40.0 + 6.0 * np.sin(3 * th)

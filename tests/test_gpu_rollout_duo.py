@@ -1,4 +1,4 @@
-"""The two-wave rollout kernel of the few-waves regime (k_rollout_car_duo: one wave integrates the dynamics, its partner wave evaluates the reward
+"""The two-wave rollout kernels of the few-waves regime (k_rollout_car_duo, k_rollout_cars_duo for 2..4 cars: one wave integrates the dynamics, its partner wave evaluates the reward
 through an LDS mailbox) does the same arithmetic in the same order as the one-wave kernel: costs and controls agree bit for bit, on the default track
 (tables in LDS), on a 960-point track (ring only in LDS), with ragged K and with several trials."""
 import json
