@@ -118,6 +118,12 @@ inline void build_track_ring(int P, const double* x, const double* y, const doub
     for (int i = 0; i < P; ++i) cert[i] = nd[(size_t)i * S + W];
 }
 
+// Rounding discipline of everything below: the compiler may NOT contract a*b + c on its own here (hipcc's default, -ffp-contract=fast, decides
+// per inlining context -- the same source then rounds differently in two kernels, and the wave-specialised rollout kernels, which evaluate parts of
+// a model step in different waves, would stop agreeing bit for bit with the one-wave kernel).  Every fused multiply-add is written as fma().
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 MP_HD double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
 
@@ -215,7 +221,7 @@ struct TireK { double fymax, thr, k2, k3; };
 
 MP_HD TireK tire_consts(double mufz, double Ca, double fxt) {                  // mufz = μ f_z
     TireK k;
-    k.fymax = fast_sqrt(fmax(mufz * mufz - fxt * fxt, 1e-8));                  // :253
+    k.fymax = fast_sqrt(fmax(fma(mufz, mufz, -(fxt * fxt)), 1e-8));            // :253
     const double rf = fast_rcp(k.fymax), rc = 1.0 / Ca;        // rc: Ca is wave-uniform
     k.thr = 3 * k.fymax * rc;                                  // tan of the switch angle :255
     k.k2 = ((Ca * Ca) * (1.0 / 3.0)) * rf;                     // C^2/(3 fy_max)
@@ -269,12 +275,12 @@ template <bool PSI>
 MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, double cd,
                                double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp) {
     const double sg = jl_sign(Vx);
-    const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0) * sg;        // :310-312
+    const double fx = fma(p.Fxmax, fmax(pedal, 0.0), p.Fxmin * fmin(pedal, 0.0) * sg);     // :310-312
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
     const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);                  // :262-272 (same derived constants as the hot path)
     const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
-    const double fx_aero = (p.CD0 + p.CD1 * fabs(Vx)) * sg;                               // :308
+    const double fx_aero = fma(p.CD1, fabs(Vx), p.CD0) * sg;                              // :308
     const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
     double fyr;
     if (Vx > 0.0 && fabs(yr / Vx) < kr.thr) fyr = tire_poly(yr / Vx, p.Car, kr);
@@ -302,48 +308,66 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     double sq, cq;
     sincos_tiny(dpsi, &sq, &cq);
     for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-    x += (Vx * cp - Vy * sp) * p.ddt;
-    y += (Vx * sp + Vy * cp) * p.ddt;
+    x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);
+    y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);
 }
 
-// env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
-// Transcendental-free (requires |delta| < pi/2, guaranteed by delta_max and actions in [-1,1]).
-// Hot path (Vx > 0, front slip in the forward half plane): branch-free up to a rarely taken large-yaw-rate fix-up,
-// tyre constants hoisted, one shared reciprocal; everything else goes through car_substep_general.
-// PSI = false drops the bookkeeping of the heading ANGLE (accumulate + wrap, :329-330): the dynamics and the reward
-// only consume sin/cos(psi), which are carried by rotation, so rollouts that do not log trajectories never need it
-// (c.psi is then left untouched = stale).
-template <bool PSI = true>
-MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1, bool renorm = true) {
-    double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r;
-    double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
-    if (__builtin_expect(renorm, 0)) {   // keep (sin,cos) pairs on the unit circle (first-order renormalisation; the norm drifts by ~1e-16 per rotation,
-                    // so callers inside long rollouts may do this every few steps only)
-        const double fp = fma(-0.5, fma(sp, sp, cp * cp), 1.5), fd = fma(-0.5, fma(sd, sd, cd * cd), 1.5);
-        sp *= fp; cp *= fp; sd *= fd; cd *= fd;
-    }
-    const double tgt = a0 * p.dmax - c.delta;
+// The action-only half of env(a): everything a model step needs that depends on the ACTION and the steering angle but not on the vehicle state
+// (position, velocities, yaw) -- the brush-model constants for sign(Vx) = +1 (:310-318) and the steering increment of a sub-step.  The steering
+// angle itself evolves from the actions alone (:295-301), so a rollout kernel may compute all of this in another wave than the integration
+// (k_rollout_car_trio); car_action_step below is the two halves back to back.
+struct ActionConsts { double pedal, fxf, fxr0; TireK kf, kr; };
+MP_HD ActionConsts car_action_consts(const CarParams& p, double a1) {
+    ActionConsts k;
+    const double pedal = a1;                                                   // :297
+    // forces and brush-model constants for sign(Vx) = +1, constant over the sub-steps (:310-318)
+    const double fx = fma(p.Fxmax, fmax(pedal, 0.0), p.Fxmin * fmin(pedal, 0.0));
+    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
+    const double fxf = lam * fx, fxr = (1 - lam) * fx;
+    k.pedal = pedal; k.fxf = fxf;
+    k.fxr0 = fxr - p.CD0;                                      // rear drive force minus the constant part of the drag (:308)
+    k.kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);
+    k.kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
+    return k;
+}
+// steering increment of one sub-step for the steering command a0 at steering angle delta (:295-296, :301), and its sin / cos
+MP_HD void car_steer_step(const CarParams& p, double a0, double delta, double* dd_out, double* sdd_out, double* cdd_out) {
+    const double tgt = fma(a0, p.dmax, -delta);
     // :295-296  min(|tgt|/dt, δ_dot_max)·sign(tgt): the magnitude is 0 when tgt is ±0, so copysign is the same function;
     // a NaN target (NaN action) must stay NaN (fmin would drop it)
     const double rmag = fmin(fabs(tgt) * p.inv_dt, p.ddotmax);
     const double rate = (tgt != tgt) ? tgt : copysign(rmag, tgt);
     const double dd = rate * p.ddt;
-    const double pedal = a1;                                                   // :297
-    // forces and brush-model constants for sign(Vx) = +1, constant over the sub-steps (:310-318)
-    const double fx = p.Fxmax * fmax(pedal, 0.0) + p.Fxmin * fmin(pedal, 0.0);
-    const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
-    const double fxf = lam * fx, fxr = (1 - lam) * fx;
-    const double fxr0 = fxr - p.CD0;                           // rear drive force minus the constant part of the drag (:308)
-    const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);
-    const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
     double sdd, cdd;
     sincos_tiny(dd, &sdd, &cdd);                               // |dd| <= ddotmax*δt = 0.0157 with the reference's parameters
     if (__builtin_expect(fabs(dd) > kTinyAngle, 0)) { sdd = sin(dd); cdd = cos(dd); }   // (user-set δ_dot_max > 179 deg/s: library path)
+    *dd_out = dd; *sdd_out = sdd; *cdd_out = cdd;
+}
+// first-order renormalisation of a (sin, cos) pair (the norm drifts by ~1e-16 per rotation, so callers inside long rollouts do this every few steps only)
+MP_HD void renorm_pair(double& sn, double& cs) {
+    const double f = fma(-0.5, fma(sn, sn, cs * cs), 1.5);
+    sn *= f; cs *= f;
+}
+// delta += dd (:301) as a rotation of (sin delta, cos delta)
+MP_HD void steer_rotate(double& sd, double& cd, double sdd, double cdd) {
+    const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd));
+    sd = s2; cd = c2;
+}
+
+// The state half of env(a): nsub Euler sub-steps (:299-333) of (x, y, psi, Vx, Vy, r) and (sin psi, cos psi) under the action constants k.  steer(sd, cd)
+// advances (sin delta, cos delta) by one sub-step -- a rotation in place, or a read of what another wave rotated.
+// Hot path (Vx > 0, front slip in the forward half plane): branch-free up to a rarely taken large-yaw-rate fix-up,
+// one shared reciprocal; everything else goes through car_substep_general.
+template <bool PSI, class SteerF>
+MP_HD void car_integrate(const CarParams& p, const ActionConsts& k, SteerF&& steer,
+                         double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp, double& sd, double& cd) {
+    const double pedal = k.pedal, fxf = k.fxf, fxr0 = k.fxr0;
+    const TireK kf = k.kf, kr = k.kr;
     // carried across sub-steps: r δt (this sub-step's "old yaw rate x δt" is the previous one's dψ), and -- in rollouts, which read
     // the position only after the action -- the position increments summed before the common factor δt is applied
     double rdt = r * p.ddt, sx = 0.0, sy = 0.0;
     auto substep = [&]() {
-        { const double s2 = fma(sd, cdd, cd * sdd), c2 = fma(cd, cdd, -(sd * sdd)); sd = s2; cd = c2; }   // delta += dd :301
+        steer(sd, cd);                                                         // delta += dd :301
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
         if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
@@ -392,11 +416,27 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
         if (it + 1 < p.nsub) substep();                                        // (odd sub-step counts: wave-uniform branch)
     }
     if (!PSI) { x = fma(sx, p.ddt, x); y = fma(sy, p.ddt, y); }
+}
+
+// env(a) for one car (a0 steering, a1 pedal, already clamped): src/envs/car_racing.jl:282-344.
+// Transcendental-free (requires |delta| < pi/2, guaranteed by delta_max and actions in [-1,1]).
+// PSI = false drops the bookkeeping of the heading ANGLE (accumulate + wrap, :329-330): the dynamics and the reward
+// only consume sin/cos(psi), which are carried by rotation, so rollouts that do not log trajectories never need it
+// (c.psi is then left untouched = stale).
+template <bool PSI = true>
+MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1, bool renorm = true) {
+    double x = c.x, y = c.y, psi = c.psi, Vx = c.Vx, Vy = c.Vy, r = c.r;
+    double sp = c.sp, cp = c.cp, sd = c.sd, cd = c.cd;
+    if (__builtin_expect(renorm, 0)) { renorm_pair(sp, cp); renorm_pair(sd, cd); }     // keep (sin,cos) pairs on the unit circle
+    double dd, sdd, cdd;
+    car_steer_step(p, a0, c.delta, &dd, &sdd, &cdd);
+    const ActionConsts k = car_action_consts(p, a1);
+    car_integrate<PSI>(p, k, [&](double& s_, double& c_) { steer_rotate(s_, c_, sdd, cdd); }, x, y, psi, Vx, Vy, r, sp, cp, sd, cd);
     // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
     double delta = c.delta;
     if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
     else delta = fma((double)p.nsub, dd, delta);
-    c.x = x; c.y = y; if (PSI) c.psi = psi; c.Vx = Vx; c.Vy = Vy; c.r = r; c.delta = delta; c.pedal = pedal;
+    c.x = x; c.y = y; if (PSI) c.psi = psi; c.Vx = Vx; c.Vy = Vy; c.r = r; c.delta = delta; c.pedal = k.pedal;
     c.sp = sp; c.cp = cp; c.sd = sd; c.cd = cd;
 }
 
@@ -412,9 +452,9 @@ MP_HD bool track_project(double px, double py, double p1x, double p1y, double pm
     const bool prev = dm2 <= dp2;
     const double p2x = prev ? pmx : ppx, p2y = prev ? pmy : ppy;
     const double ux = px - p1x, uy = py - p1y, vx = p2x - p1x, vy = p2y - p1y;
-    const double t = (ux * vx + uy * vy) * fast_rcp(vx * vx + vy * vy);        // :87
-    const double ex = (p1x + t * vx) - px, ey = (p1y + t * vy) - py;           // :88-89
-    const double dist = fast_sqrt(ex * ex + ey * ey);
+    const double t = fma(ux, vx, uy * vy) * fast_rcp(fma(vx, vx, vy * vy));    // :87
+    const double ex = fma(t, vx, p1x) - px, ey = fma(t, vy, p1y) - py;         // :88-89
+    const double dist = fast_sqrt(fma(ex, ex, ey * ey));
     *dist_out = dist;
     return dist < lane_w;                                                      // :90
 }
@@ -455,7 +495,7 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
         } else {
             // far from the anchor (or a track that folds back on itself): scan the anchor's neighbour list up to the triangle bound
             mi = a0; best = d0;
-            const double bound = 2.0 * fast_sqrt(fmax(D02, 0.0)) + 1e-6;
+            const double bound = fma(2.0, fast_sqrt(fmax(D02, 0.0)), 1e-6);
             bool closed = false;
             for (int c = 1; c < tk.nbrw; ++c) {
                 if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
@@ -542,9 +582,12 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
     if (!within) rew += -1000000.0;
     if (exceed_beta(p, Vx, Vy)) rew += -5000.0;                                // exceed_β :184-189
     rew += -dist;
-    rew += 2.0 * fast_sqrt(Vx * Vx + Vy * Vy);
+    rew = fma(2.0, fast_sqrt(fma(Vx, Vx, Vy * Vy)), rew);
     return rew;
 }
+
+// one step's term of the control cost γ U_orig' Σ^-1 (V - U_orig) for a two-dimensional action (mppi_mpopi_policies.jl:272)
+MP_HD double control_cost_term(double g0, double d0, double g1, double d1) { return fma(g0, d0, g1 * d1); }
 
 // ---- MountainCar (continuous) -------------------------------------------------------------------
 struct McParams { double min_pos, max_pos, max_speed, goal_pos, goal_vel, power, gravity; int max_steps; };
@@ -606,5 +649,8 @@ MP_HD void cp_step(const CpParams& p, double* s, int* t, int* done, double a) {
 }
 
 MP_HD double cp_reward(int done) { return done ? 0.0 : 1.0; }
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
 
 }  // namespace mpopis

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
             e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
             u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
         }
-        if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272 (unclamped V; γ = 0 in every reference config)
+        if (__builtin_expect(gv != nullptr, 0)) cc += control_cost_term(gv[t * as], v0 - Uo[t * as], gv[t * as + 1], v1 - Uo[t * as + 1]);   // :272 (unclamped V; γ = 0 in every reference config)
         const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1); // get_model_controls
         car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
         const double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
                 e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
                 u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
             }
-            if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+            if (__builtin_expect(gv != nullptr, 0)) cc += control_cost_term(gv[t * as], v0 - Uo[t * as], gv[t * as + 1], v1 - Uo[t * as + 1]);   // :272
             const double a0 = clampd_u(v0, lo0, hi0), a1 = clampd_u(v1, lo1, hi1);
             car_action_step<false>(p, s, a0, a1, (t & 3) == 0);
             const int slot = t & 1;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
             e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
             u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
         }
-        if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+        if (__builtin_expect(gv != nullptr, 0)) cc += control_cost_term(gv[t * as], v0 - Uo[t * as], gv[t * as + 1], v1 - Uo[t * as + 1]);   // :272
         const double a0 = clampd_v(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd_v(v1, sh_bnd[c][2], sh_bnd[c][3]);   // get_model_controls (NaN passes through)
         car_action_step<LOG>(p, s, a0, a1, (t & 3) == 0);                      // unit-circle renormalisation every 4th step
         double rew = car_reward(p, tk, s.x, s.y, s.Vx, s.Vy, &s.near);
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
             const double xq = __shfl(s.x, q * S + j, 64), yq = __shfl(s.y, q * S + j, 64);
             if (q > c) {
                 const double dx = xq - s.x, dy = yq - s.y;
-                const double dd = fast_sqrt(dx * dx + dy * dy);                // 1 ulp (car_dynamics.h); coincident cars give 1e-150, not 0
+                const double dd = fast_sqrt(fma(dx, dx, dy * dy));             // 1 ulp (car_dynamics.h); coincident cars give 1e-150, not 0
                 rew += -dd;
                 if (dd <= 4.0) rew += -11000.0;
             }
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
                 e0 = Eb[(size_t)(t + 1) * as * K]; e1 = Eb[(size_t)(t + 1) * as * K + K];
                 u0 = Ub[(t + 1) * as]; u1 = Ub[(t + 1) * as + 1];
             }
-            if (__builtin_expect(gv != nullptr, 0)) cc += gv[t * as] * (v0 - Uo[t * as]) + gv[t * as + 1] * (v1 - Uo[t * as + 1]);   // :272
+            if (__builtin_expect(gv != nullptr, 0)) cc += control_cost_term(gv[t * as], v0 - Uo[t * as], gv[t * as + 1], v1 - Uo[t * as + 1]);   // :272
             const double a0 = clampd_v(v0, sh_bnd[c][0], sh_bnd[c][1]), a1 = clampd_v(v1, sh_bnd[c][2], sh_bnd[c][3]);
             car_action_step<false>(p, s, a0, a1, (t & 3) == 0);
             const int slot = t & 1;
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
             const double xq = __shfl(x, q * S + j, 64), yq = __shfl(y, q * S + j, 64);
             if (q > c) {
                 const double dx = xq - x, dy = yq - y;
-                const double dd = fast_sqrt(dx * dx + dy * dy);
+                const double dd = fast_sqrt(fma(dx, dx, dy * dy));
                 rew += -dd;
                 if (dd <= 4.0) rew += -11000.0;
             }
