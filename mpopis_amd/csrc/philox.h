@@ -67,7 +67,7 @@ __device__ __forceinline__ void sincos_2pi_u32(uint32_t w, const double* __restr
 // (w0, w1) and on (w2, w3), radius word first, with 32-bit uniforms u = (w + 0.5) 2^-32 in (0, 1).  Round 2 spent a whole call on one pair
 // (two 53-bit uniforms); the twenty v_mad_u64_u32 of a call were the largest single item of the fused sampler, whose VALU work does NOT overlap
 // the FP64 MFMAs of its neighbours (tools/mfma_valu_overlap.hip: the two serialise on a SIMD).  What 32 bits cost: the radius sqrt(-2 log u)
-// takes 2^32 values and stops at 6.66 (mass beyond: 2.7e-11 -- one draw in 1400 full C5 steps); neighbouring radii differ by <= 4e-10 relative in
+// takes 2^32 values and stops at 6.76 = sqrt(-2 log 2^-33) (mass beyond: 1.4e-11 -- one draw in 2700 full C5 steps); neighbouring radii differ by <= 4e-10 relative in
 // the bulk.  The reference's stream (MersenneTwister + ziggurat) is not reproduced either way; oracle/mpopis_oracle.c (orc_philox_normals)
 // defines the same stream with libm.
 __device__ __forceinline__ void box_muller_u32(uint32_t wr, uint32_t wa, const double* __restrict__ tab, double* z0, double* z1) {
