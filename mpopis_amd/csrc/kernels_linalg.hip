@@ -72,9 +72,10 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
     __syncthreads();
     const int li = lane & 15, lk = lane >> 4;
     auto factor_diag_inv = [&](int j0) {
+        const int rounds = (j0 + kNB >= m) ? min(4, (n - j0 + 3) / 4) : 4;     // last block: only the sub-blocks that hold matrix rows
         const bool bad = diag16_factor(lane,
             [&](int i, int c) { return W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw]; },
-            [&](int i, int c, double v) { W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
+            [&](int i, int c, double v) { W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh, rounds);
         if (bad && lane == 0) failed = 1;
     };
     // rows r0 .. r0+15 of the panel below the diagonal block: L21 tile = A21 tile * L11^-T on the matrix cores (in place: every lane

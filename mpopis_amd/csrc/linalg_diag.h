@@ -23,8 +23,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {     // src is 
 // Out: the factor through `store(i, c, v)` (c <= i) and, for the panel solve that follows (panel_solve_tile), sh.L = the factor
 // with zeros above the diagonal and sh.T[G] = the inverses of the four diagonal 4x4 sub-blocks.  Returns true on a non-positive pivot.
 struct DiagScratch { double Lc[2][kNB][5], T[4][4][4], L[kNB][kNB + 1]; };
+// rounds (1..4, wave-uniform): sub-block columns to process.  A LAST diagonal block whose rows beyond 4 rounds are the identity tail of the padding
+// (n = 100: the seventh block holds rows 96..99 and twelve identity rows) needs only its leading rounds -- the identity rows are already their own
+// factor, nothing below the block consumes sh.T -- which takes ~0.5 us per skipped round off the serial chain.
 template <class LoadF, class StoreF>
-__device__ __forceinline__ bool diag16_factor(int lane, LoadF load, StoreF store, DiagScratch& sh) {
+__device__ __forceinline__ bool diag16_factor(int lane, LoadF load, StoreF store, DiagScratch& sh, int rounds = 4) {
     auto& Lc = sh.Lc;
     const int i = lane & 15, g = lane >> 4;
     double e[4];
@@ -38,6 +41,7 @@ __device__ __forceinline__ bool diag16_factor(int lane, LoadF load, StoreF store
     };
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
+        if (G >= rounds) break;
         const int buf = G & 1;
         // (a) the 4x4 diagonal sub-block (lower part), from lanes (4G + r, G)
         const double s00 = bcast_lane(e[0], 4 * G + 0 + 16 * G);
