@@ -306,9 +306,9 @@ __global__ void __launch_bounds__(ROWS ? 512 : 256, ROWS ? 1 : 2) k_wcov_mfma_pa
     };
     if (kbeg < kend) load_chunk(kbeg);
     if (ROWS) {
-        // two LDS images, one barrier per chunk, one workgroup per CU: a wave writes chunk c+1 (loaded during chunk c-1) into the other image and
-        // issues the loads of chunk c+2, then runs the 112 MFMAs of chunk c -- nothing between two MFMA phases but those ~90 issue slots, where the
-        // single-image form had two barriers and the whole staging pass (the matrix pipe idled ~45 % of the kernel)
+        // two LDS images, one barrier per chunk, one workgroup (8 waves) per CU: a wave writes its share of chunk c+1 (loaded during chunk c-1) into the
+        // other image and issues the loads of chunk c+2 BETWEEN the MFMA groups of its half of chunk c (56 MFMAs) -- where the single-image form had two
+        // barriers and the whole staging pass between two MFMA phases (the matrix pipe idled ~45 % of the kernel)
         double* Xs1 = wsl + (costp ? wgper : 0);
         if (kbeg < kend) { stage_chunk(Xs, kbeg); load_chunk(kbeg + KC); }      // (clamped addresses: a chunk beyond the range loads valid memory)
         __syncthreads();
