@@ -189,8 +189,9 @@ void launch_gather_mean_strided(const double* X, const int32_t* idx, const doubl
 
 // kernels_ce.hip: the whole CE proposal update (elite mean, Σ_est covariance + ridge, pol.U += μ′) in one launch for small elite sets
 bool ce_cov_small_ok(int cs, int m, int est);
-void launch_ce_cov_small(const double* E, const int32_t* order, double* mu, double* S, double* Ucur, int B, int cs, int K, int m, int est, double ridge,
-                         const int* active, hipStream_t s);
+bool ce_sort_fusable(int K);
+void launch_ce_cov_small(const double* E, int32_t* order, double* mu, double* S, double* Ucur, int B, int cs, int K, int m, int est, double ridge,
+                         int* active, hipStream_t s, const double* cost = nullptr /* non-null (K <= 256): also sortperm(cost) -> order and the elite early break */);
 
 // kernels_select.hip
 void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s,

@@ -126,15 +126,19 @@ int mpopis_handle::ais_update(int n, bool injected) {
             launch_trtri_fro(cur_L, cur_Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv);
             (void)hipEventRecord(ev_join[0], xstream[0]);
         }
-        time_begin(5);
-        // (:pmcmppi's alias-table buffers are free under :cemppi / :cmamppi: scratch of the chip-wide rank sort)
-        launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream, d_accept, d_alias_need);   // :455 / :563 and the early break :458-461 / :566-569
-        time_end();
+        static const int env_small = [] { const char* e = getenv("MPOPIS_CE_SMALL"); return e ? atoi(e) : 1; }();      // 0: always the general path; 2: small kernel, sort in its own launch (A/B, tests)
+        const bool ce_small = pol == MPOPIS_POL_CEMPPI && env_small && ce_cov_small_ok(cs, m_elite, cfg.sigma_est);
+        const bool ce_sorts = ce_small && env_small != 2 && ce_sort_fusable(K);           // the CE kernel sorts (and breaks) itself
+        if (!ce_sorts) {
+            time_begin(5);
+            // (:pmcmppi's alias-table buffers are free under :cemppi / :cmamppi: scratch of the chip-wide rank sort)
+            launch_sortperm(d_cost, d_order, B, K, m_elite, d_active, stream, d_accept, d_alias_need);   // :455 / :563 and the early break :458-461 / :566-569
+            time_end();
+        }
         if (pol == MPOPIS_POL_CEMPPI) {                                                       // :464-465
-            static const int env_small = [] { const char* e = getenv("MPOPIS_CE_SMALL"); return e ? atoi(e) : 1; }();      // 0: always the general path (A/B, tests)
-            if (env_small && ce_cov_small_ok(cs, m_elite, cfg.sigma_est)) {
+            if (ce_small) {
                 time_begin(4);
-                launch_ce_cov_small(d_E, d_order, d_mu, d_Sig, d_Ucur, B, cs, K, m_elite, cfg.sigma_est, 10e-9, d_active, stream);
+                launch_ce_cov_small(d_E, d_order, d_mu, d_Sig, d_Ucur, B, cs, K, m_elite, cfg.sigma_est, 10e-9, d_active, stream, ce_sorts ? d_cost : nullptr);
                 time_end();
                 return MPOPIS_OK;
             }

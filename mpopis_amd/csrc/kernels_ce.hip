@@ -25,24 +25,65 @@ __device__ __forceinline__ void ce_decode(int q, int* ta, int* tb) {    // q -> 
 // S = X X' / m and Q = (X.X)(X.X)' on the matrix cores (X = centred elite matrix in LDS, zero padded to 16-row tiles and 4-column k-steps):
 // __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc) with av = X[ta 16 + li][4kk + lk], bv = X[tb 16 + li][4kk + lk] accumulates
 // acc[r] = (tile ta)(tile tb)' at (row li, column lk + 4r) -- the idiom of kernels_linalg.hip / kernels_mfma.hip.
-__global__ void __launch_bounds__(kCeThreads) k_ce_cov_small(const double* __restrict__ E, const int32_t* __restrict__ order, double* __restrict__ mu_out,
+// cost != nullptr (K <= kCeSortMax): the kernel also does what launch_sortperm would have done before it -- order = sortperm(cost) as a rank sort
+// ((cost, index) order == Julia's stable sortperm; same code as k_sortperm_rank) and the elite early break (:458-461: max_j |c[order[j+1]] -
+// c[order[j]]| < 10e-3 over the elite set => active[b] = 0 and nothing of this iteration is applied) -- one launch less per AIS iteration.
+constexpr int kCeSortMax = 256;
+__global__ void __launch_bounds__(kCeThreads) k_ce_cov_small(const double* __restrict__ E, int32_t* __restrict__ order, double* __restrict__ mu_out,
                                                              double* __restrict__ Sg, double* __restrict__ Ucur, int cs, int K, int m, int est,
-                                                             double ridge, const int* active) {
+                                                             double ridge, int* active, const double* __restrict__ cost) {
     MPOPIS_HI_PRIO();
     const int b = blockIdx.x;
     if (active && !active[b]) return;
+    __shared__ int sh_idx[64];
+    if (cost) {
+        __shared__ __attribute__((aligned(16))) double c[kCeSortMax], sc[kCeSortMax];
+        __shared__ double eb_red[kCeThreads / 64];
+        __shared__ int sh_broke;
+        const int i = threadIdx.x;
+        const double ci = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+        if (i < kCeSortMax) { c[i] = ci; sc[i] = INFINITY; }
+        if (i == 0) sh_broke = 0;
+        __syncthreads();
+        if (i < K) {
+            int rank = 0;
+            const int K4 = K & ~3;
+            for (int j = 0; j < K4; j += 4) {
+                const double c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
+                rank += ((c0 < ci) || (c0 == ci && j < i)) + ((c1 < ci) || (c1 == ci && j + 1 < i)) + ((c2 < ci) || (c2 == ci && j + 2 < i)) +
+                        ((c3 < ci) || (c3 == ci && j + 3 < i));
+            }
+            for (int j = K4; j < K; ++j) rank += ((c[j] < ci) || (c[j] == ci && j < i));
+            order[(size_t)b * K + rank] = i; sc[rank] = ci;
+            if (rank < m) sh_idx[rank] = i;
+        }
+        __syncthreads();
+        if (m >= 2 && active) {                                  // elite early break on the sorted costs (as elite_break_tail, kernels_select.hip)
+            double mx = -INFINITY;
+            for (int j = threadIdx.x; j + 1 < m; j += kCeThreads) mx = fmax(mx, fabs(sc[j + 1] - sc[j]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+            if ((threadIdx.x & 63) == 0) eb_red[threadIdx.x >> 6] = mx;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kCeThreads / 64; ++w) mx = fmax(mx, eb_red[w]);
+                if (mx < 10e-3) { active[b] = 0; sh_broke = 1; }
+            }
+            __syncthreads();
+            if (sh_broke) return;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) double sh_ce[];
     const int nt = (cs + 15) / 16, rows = nt * 16, mpad = (m + 3) & ~3, ld = mpad + 1;      // odd row stride: conflict-free operand reads
     double* X = sh_ce;                                           // [rows][ld]
     double* dg = X + (size_t)rows * ld;                          // [rows] diagonal of S
     __shared__ double red[2 * kCeWaves];
     __shared__ double sh_lam, sh_f;
-    __shared__ int sh_idx[64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     const double* Eb = E + (size_t)b * cs * K;
     const int32_t* ob = order + (size_t)b * K;
     // ---- gather (every thread's loads in flight together: index -> value is two dependent global round trips), then mean + centre -----------
-    if (tid < m) sh_idx[tid] = ob[tid];
+    if (!cost && tid < m) sh_idx[tid] = ob[tid];
     for (int e = tid; e < rows * ld; e += kCeThreads) X[e] = 0.0;
     __syncthreads();
     for (int e0 = tid; e0 < cs * m; e0 += kCeThreads * 8) {
@@ -175,11 +216,12 @@ size_t ce_cov_small_lds(int cs, int m, int est) {
     return (rows * ld + rows) * sizeof(double);
 }
 bool ce_cov_small_ok(int cs, int m, int est) { return cs <= 128 && m >= 2 && m <= 64 && ce_cov_small_lds(cs, m, est) <= 150 * 1024; }
-void launch_ce_cov_small(const double* E, const int32_t* order, double* mu, double* S, double* Ucur, int B, int cs, int K, int m, int est, double ridge,
-                         const int* active, hipStream_t s) {
+bool ce_sort_fusable(int K) { return K <= kCeSortMax; }
+void launch_ce_cov_small(const double* E, int32_t* order, double* mu, double* S, double* Ucur, int B, int cs, int K, int m, int est, double ridge,
+                         int* active, hipStream_t s, const double* cost) {
     static std::atomic<unsigned long long> seen{0};
     ensure_dyn_lds((const void*)k_ce_cov_small, 150 * 1024, seen);
-    hipLaunchKernelGGL(k_ce_cov_small, dim3(B), dim3(kCeThreads), ce_cov_small_lds(cs, m, est), s, E, order, mu, S, Ucur, cs, K, m, est, ridge, active);
+    hipLaunchKernelGGL(k_ce_cov_small, dim3(B), dim3(kCeThreads), ce_cov_small_lds(cs, m, est), s, E, order, mu, S, Ucur, cs, K, m, est, ridge, active, cost);
 }
 
 }  // namespace mpopis

@@ -611,3 +611,29 @@ def test_level2_odd_sizes_car(eng_mod, oracle, track):
         assert np.max(np.abs(got["control"][0] - ref["control"])) < 1e-8, kind
         assert np.max(np.abs(eng.get_U()[0] - pol.U)) < 1e-8, kind
         eng.close()
+
+
+@pytest.mark.parametrize("kind,K", [("cemppi", 150), ("cemppi", 400), ("cmamppi", 150)])
+def test_elite_early_break(eng_mod, oracle, track, kind, K):
+    """The elite early break (:458-461 / :566-569: max gap of the sorted elite costs < 10e-3 => leave the AIS loop, nothing of the iteration applied):
+    slot 0 gets noise so small that all its costs coincide to 1e-6 and breaks in the first iteration, slot 1 runs on.  K = 150 takes the CE kernel that
+    sorts and breaks itself (kernels_ce.hip), K = 400 and :cmamppi the sort kernels' tail."""
+    T, N, B = 50, 4, 2
+    cs = 2 * T
+    rng = np.random.default_rng(77)
+    eng = eng_mod.Engine("car", 1, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, cma_sigma=0.75, cov=[0.0625, 0.1], track=track)
+    envs, pols = zip(*[make_oracle(oracle, track, kind, 1, K, T, N=N) for _ in range(B)])
+    Z = rng.standard_normal((B, N, K, cs))
+    Z[0] *= 1e-9
+    di = rng.integers(0, K, (B, N - 1, K)).astype(np.int32)
+    du = rng.random((B, N - 1, K))
+    refs = [pols[b](envs[b], Z[b], di[b], du[b]) for b in range(B)]
+    got = eng.policy_step(Z, di, du)
+    assert refs[0]["iters_run"] == 1 and refs[1]["iters_run"] == N          # the scenario is what it claims to be
+    U_dev = eng.get_U()
+    for b in range(B):
+        assert got["iters_run"][b] == refs[b]["iters_run"]
+        assert rel_err(got["cost"][b], refs[b]["cost"]) < 1e-7
+        assert np.max(np.abs(got["control"][b] - refs[b]["control"])) < 1e-7
+        assert np.max(np.abs(U_dev[b] - pols[b].U)) < 1e-7
+    eng.close()
