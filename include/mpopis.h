@@ -38,8 +38,9 @@ extern "C" {
  * mpopis_gather_summary, and the error code MPOPIS_ERR_NUMERIC.  A version-1 caller keeps working against a version-2 library (nothing was
  * removed or changed in meaning); a caller that needs the newer entry points checks mpopis_abi_version() >= 2.
  * Error precedence when several slots / kernels fail in one call: MPOPIS_ERR_HIP > MPOPIS_ERR_ACTION > MPOPIS_ERR_NOT_PD > MPOPIS_ERR_NUMERIC --
- * the version-1 codes keep their order (numeric minimum) and are never hidden by MPOPIS_ERR_NUMERIC. */
-#define MPOPIS_ABI_VERSION 2
+ * the version-1 codes keep their order (numeric minimum) and are never hidden by MPOPIS_ERR_NUMERIC.
+ * 3: + mpopis_policy_call (control = pol(env) with a single host wait).  Nothing removed or changed in meaning. */
+#define MPOPIS_ABI_VERSION 3
 
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };
 
@@ -153,6 +154,18 @@ int  mpopis_rollout_costs(mpopis_handle *h, const double *x0, const double *U, c
 int  mpopis_policy_step(mpopis_handle *h, const mpopis_noise *noise,
                         double *control, double *cost, double *weights, double *E_out,
                         int32_t *resample_idx0, int32_t *iters_run);
+
+/* control = pol(env) exactly as the reference's harness calls it once per MPC step, synchronously, for one env the HOST owns
+ * (src/examples/car_example.jl:203-207 `act = pol(env); env(act)`; mountaincar_example.jl:150-153): in ONE call and ONE host wait
+ *   x, t, done   -> state(env), env.t, env.done of every slot (B*ss, B, B; x NULL: keep the resident state; t / done may be NULL)
+ *   U_inout      -> in: pol.U (B*cs) before the call; out: the rolled pol.U (get_controls_roll_U!, src/utils.jl:88-101).  NULL: the
+ *                   resident pol.U is used and rolled on the device only
+ *   noise        -> NULL: device Philox streams (the production path); non-NULL: as mpopis_policy_step
+ *   control B*as, cost B*K, weights B*K, iters_run B: outputs, any may be NULL
+ * Equivalent to mpopis_set_state + mpopis_set_U + mpopis_policy_step + mpopis_get_U (four host waits); the small arrays travel through a
+ * pinned, device-mapped mailbox owned by the handle instead of copy commands. */
+int  mpopis_policy_call(mpopis_handle *h, const double *x, const int32_t *t, const int32_t *done, double *U_inout,
+                        const mpopis_noise *noise, double *control, double *cost, double *weights, int32_t *iters_run);
 
 /* env(action) for the resident real envs + reward(env): src/envs/car_racing.jl:238-250,201-213;
  * multi-car_racing.jl:200-207,145-158; mountaincar_example.jl:4-22.  action B*as, reward B out. */

@@ -4,7 +4,7 @@
 # there (expect to fix typos on first load); it is the thin `ccall` layer a MPOPIS maintainer adds.  It plugs in exactly where the
 # reference already dispatches on the env type for its EnvPool backend
 # (src/mppi_mpopi_policies.jl:148 vs :186, :240 vs :261): more specific methods of
-#     (pol::AbstractPathIntegralPolicy)(env)         -> mpopis_policy_step
+#     (pol::AbstractPathIntegralPolicy)(env)         -> mpopis_policy_call (one ccall, one host wait per MPC step)
 #     simulate_model(pol, env, E, Σ_inv, U_orig)     -> mpopis_rollout_costs
 # for env::CarRacingEnv / MultiCarRacingEnv / MountainCarEnv / CartPoleEnv.  Every other env type keeps falling
 # through to the Julia CPU methods unchanged.  Policy symbols, constructors, `get_policy`,
@@ -22,7 +22,7 @@ const LIB = get(ENV, "MPOPIS_HIP_LIB", joinpath(@__DIR__, "..", "mpopis_amd", "l
 
 function __init__()
     v = ccall((:mpopis_abi_version, LIB), Cint, ())
-    v >= 2 || error("libmpopis_hip.so speaks ABI version $v; this binding needs >= 2 (mpopis_seed_slots, mpopis_get_Sigma, MPOPIS_ERR_NUMERIC)")
+    v >= 3 || error("libmpopis_hip.so speaks ABI version $v; this binding needs >= 3 (mpopis_policy_call)")
 end
 
 # mirrors `mpopis_config` (include/mpopis.h) field for field
@@ -51,10 +51,15 @@ elite(pol) = 0.8
 cma_sigma(pol::CMAMPPI_Policy) = pol.σ
 cma_sigma(pol) = 1.0
 # MPOPIS_SIGMA_EST_*: CEMPPI_Policy stores the estimator object, not the symbol (src/mppi_mpopi_policies.jl:386,414-426)
-sigma_est(pol::CEMPPI_Policy) = sigma_est(pol.Σ_estimation_method)
-sigma_est(::MPOPIS.SimpleCovariance) = 0                                                  # :mle
-sigma_est(m::MPOPIS.LinearShrinkage) = Dict(:ss => 1, :lw => 2, :rblw => 3, :oas => 4)[m.shrinkage]
+# Told apart by type NAME (SimpleCovariance / LinearShrinkage are CovarianceEstimation.jl types; going by name needs neither that package in
+# this module's environment nor MPOPIS re-exporting them).
+sigma_est(pol::CEMPPI_Policy) = sigma_est_id(pol.Σ_estimation_method)
 sigma_est(pol) = 0
+function sigma_est_id(m)
+    nameof(typeof(m)) === :SimpleCovariance && return 0                                   # :mle
+    nameof(typeof(m)) === :LinearShrinkage || error("MPOPISHip: unknown Σ estimation method $(typeof(m))")
+    return Dict(:ss => 1, :lw => 2, :rblw => 3, :oas => 4)[m.shrinkage]
+end
 
 car_param_vector(env::CarRacingEnv) = Float64[getfield(env.params, f) for f in fieldnames(typeof(env.params))] |>
                                       v -> vcat(v, env.dt, env.δt)
@@ -64,13 +69,22 @@ track_of(env::MultiCarRacingEnv) = env.envs[1].track
 
 check(h, rc) = rc == 0 ? nothing : error(unsafe_string(ccall((:mpopis_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
 
-const HANDLES = IdDict{Any,Ptr{Cvoid}}()       # one engine handle per policy object
+# One engine handle per policy object.  Weak keys: the table must not keep a policy alive (its finalizer destroys the handle; an IdDict
+# entry would pin the policy for ever, and the finalizer would never run).  Policies are `mutable struct`s, so keys compare by identity.
+const HANDLES = WeakKeyDict{Any,Ptr{Cvoid}}()
+# seed!(pol, s) issued BEFORE the first pol(env) -- the order the reference harness uses (src/examples/car_example.jl:187-188 precede :205) --
+# is kept here and consumed when the handle is created, so the harness seed reaches the device streams.
+const PENDING_SEED = WeakKeyDict{Any,UInt64}()
+
+# Device seed of a policy nobody seeded: taken from a COPY of pol.rng (deterministic given the policy's own rng state, and pol.rng is not advanced).
+default_seed(pol) = rand(copy(pol.rng), UInt64)
 
 function handle(pol, env)
     get!(HANDLES, pol) do
         kind, ncars = env_kind(env)
+        seed0 = haskey(PENDING_SEED, pol) ? pop!(PENDING_SEED, pol) : default_seed(pol)
         cfg = Config(0, kind, ncars, policy_id(pol), pol.params.num_samples, pol.params.horizon, 1, ais_its(pol),
-                     sigma_est(pol), pol.params.log, pol.params.λ, pol.params.α, lam_ais(pol), elite(pol), cma_sigma(pol), rand(UInt64))
+                     sigma_est(pol), pol.params.log, pol.params.λ, pol.params.α, lam_ais(pol), elite(pol), cma_sigma(pol), seed0)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:mpopis_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, out)
         rc == 0 || error(unsafe_string(ccall((:mpopis_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -104,14 +118,13 @@ function hip_policy_call(pol::AbstractPathIntegralPolicy, env)
     h = handle(pol, env)
     K, as = pol.params.num_samples, pol.params.as
     x = Vector{Float64}(MPOPIS.state(env)); t = Int32[env_t(env)]; done = Int32[env.done]
-    control = Vector{Float64}(undef, as); cost = Vector{Float64}(undef, K); w = Vector{Float64}(undef, K)
+    want_log = pol.params.log                              # costs / weights are only copied back when the logger wants them
+    control = Vector{Float64}(undef, as); cost = Vector{Float64}(undef, want_log ? K : 0); w = Vector{Float64}(undef, want_log ? K : 0)
+    # ONE ccall, one host wait: state in, pol.U in and (rolled in place, same array as params.U₀) out, control / cost / weights out
     GC.@preserve x t done control cost w begin
-        check(h, ccall((:mpopis_set_state, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}), h, x, t, done))
-        check(h, ccall((:mpopis_set_U, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, pol.U))
-        check(h, ccall((:mpopis_policy_step, LIB), Cint,
-                       (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
-                       h, C_NULL, control, cost, w, C_NULL, C_NULL, C_NULL))
-        check(h, ccall((:mpopis_get_U, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, pol.U))   # rolled in place (same array as params.U₀)
+        check(h, ccall((:mpopis_policy_call, LIB), Cint,
+                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                       h, x, t, done, pol.U, C_NULL, control, want_log ? pointer(cost) : C_NULL, want_log ? pointer(w) : C_NULL, C_NULL))
     end
     if pol.params.log
         pol.logger.traj_costs = cost; pol.logger.traj_weights = w
@@ -152,12 +165,23 @@ end
 
 # Random.seed!(pol, seed) also reseeds the device streams.  NOTE for the maintainer: once a policy is bound to a handle, E is drawn on the device
 # from Philox4x32-10 streams keyed by this seed (slot b of a handle draws from seed + b, hence `seed - 1` below for the one-slot handles this
-# binding creates: mpopis_seed gives slot 0 the key `arg + 1`), NOT from `pol.rng`; `pol.rng` is still seeded so that code which reads it
-# directly (state noise in the example harness) behaves as before.  Results therefore differ from a CPU run with the same seed in the draws,
-# not in the algorithm -- pass explicit noise (`mpopis_noise`) to compare the two paths number for number.
-function MPOPIS.seed!(pol::AbstractPathIntegralPolicy, seed::Integer)
+# binding creates: mpopis_seed / mpopis_create give slot 0 the key `arg + 1`), NOT from `pol.rng`; `pol.rng` is still seeded so that code which
+# reads it directly (state noise in the example harness) behaves as before.  Results therefore differ from a CPU run with the same seed in the
+# draws, not in the algorithm -- pass explicit noise (`mpopis_noise`) to compare the two paths number for number.
+# A seed that arrives before the handle exists (the harness order: construct, seed!, first pol(env)) is parked in PENDING_SEED and becomes the
+# handle's creation seed; tests/abi_client.c runs the same three-step order against the C ABI (lazy handle, parked seed) and checks that two
+# runs give identical controls.
+# The method is MORE SPECIFIC than the reference's `Random.seed!(pol::AbstractPathIntegralPolicy, seed)` (src/MPOPIS.jl:54: concrete policy
+# types, `seed::Integer`), so nothing is overwritten (method overwriting is an error during precompilation).
+const BoundPolicy = Union{MPPI_Policy, GMPPI_Policy, IMPPI_Policy, CEMPPI_Policy, CMAMPPI_Policy, μAISMPPI_Policy, μΣAISMPPI_Policy, PMCMPPI_Policy}
+function MPOPIS.seed!(pol::BoundPolicy, seed::Integer)
     MPOPIS.Random.seed!(pol.rng, seed)
-    haskey(HANDLES, pol) && check(HANDLES[pol], ccall((:mpopis_seed, LIB), Cint, (Ptr{Cvoid}, UInt64), HANDLES[pol], UInt64(seed - 1)))
+    s = (seed - 1) % UInt64                                # wraps like the C side's uint64_t arithmetic
+    if haskey(HANDLES, pol)
+        check(HANDLES[pol], ccall((:mpopis_seed, LIB), Cint, (Ptr{Cvoid}, UInt64), HANDLES[pol], s))
+    else
+        PENDING_SEED[pol] = s
+    end
     pol
 end
 

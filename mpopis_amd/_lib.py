@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpopis_seed", "mpopis_seed_slots", "mpopis_get_Sigma", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
     "mpopis_env_query", "mpopis_get_trajectories", "mpopis_set_state_noise", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
-    "mpopis_set_overlap", "mpopis_comm_unique_id", "mpopis_comm_init", "mpopis_gather_summary", "mpopis_comm_destroy",
+    "mpopis_policy_call", "mpopis_set_overlap", "mpopis_comm_unique_id", "mpopis_comm_init", "mpopis_gather_summary", "mpopis_comm_destroy",
 ]
 
 
@@ -82,6 +82,7 @@ def lib():
         L.mpopis_get_Sigma.argtypes = [H, _dp]
         L.mpopis_rollout_costs.argtypes = [H, _dp, _dp, _dp, _dp, _dp, _dp]
         L.mpopis_policy_step.argtypes = [H, C.POINTER(Noise), _dp, _dp, _dp, _dp, _ip, _ip]
+        L.mpopis_policy_call.argtypes = [H, _dp, _ip, _ip, _dp, C.POINTER(Noise), _dp, _dp, _dp, _ip]
         L.mpopis_env_step.argtypes = [H, _dp, _dp]
         L.mpopis_env_query.argtypes = [H, _dp, _ip, _dp, _dp]
         L.mpopis_get_trajectories.argtypes = [H, _dp]

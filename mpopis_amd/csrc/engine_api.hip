@@ -43,6 +43,30 @@ __global__ void k_scaled_copy_f64(const double* s, size_t sstride, const double*
     if (i < n) d[(size_t)b * n + i] = (scale ? scale[b] : 1.0) * s[(size_t)b * sstride + i];
 }
 
+// mpopis_policy_call: the hand-over kernels between the pinned mailbox (device-mapped host memory) and the resident buffers.
+struct CallBox { double *x, *U, *control, *Uout; int *t, *done, *status, *iters, *coop; };
+static CallBox call_box(double* base, int B, int ss, int cs, int as) {
+    CallBox m;
+    m.x = base; m.U = m.x + (size_t)B * ss; m.control = m.U + (size_t)B * cs; m.Uout = m.control + (size_t)B * as;
+    m.t = (int*)(m.Uout + (size_t)B * cs); m.done = m.t + B; m.status = m.done + B; m.iters = m.status + B; m.coop = m.iters + B;
+    return m;
+}
+static size_t call_box_bytes(int B, int ss, int cs, int as) { return sizeof(double) * ((size_t)B * (ss + 2 * cs + as)) + sizeof(int) * ((size_t)4 * B + 2); }
+__global__ void k_call_in(CallBox m, double* x, double* U, int* t, int* done, int nx, int nu, int B, int flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if ((flags & 1) && i < nx) x[i] = m.x[i];
+    if ((flags & 2) && i < nu) U[i] = m.U[i];
+    if (i < B) { if (flags & 4) t[i] = m.t[i]; if (flags & 8) done[i] = m.done[i]; }
+}
+__global__ void k_call_out(CallBox m, const double* control, const double* U, const int* status, const int* iters, const int* coop, int nc, int nu, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nc) m.control[i] = control[i];
+    if (i < nu) m.Uout[i] = U[i];
+    if (i < B) { m.status[i] = status[i]; m.iters[i] = iters[i]; }
+    if (i == 0) *m.coop = coop ? *coop : 0;
+    __threadfence_system();
+}
+
 static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
 static void copy_f64(const double* s_, double* d, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_copy_f64, dim3((n + 255) / 256), dim3(256), 0, s, s_, d, n); }
 
@@ -87,6 +111,15 @@ static hipError_t wait_stream(hipStream_t s) {
     return hipStreamSynchronize(s);
 }
 
+static int fold_status(mpopis_handle* h, const int* per_slot) {
+    int st = 0;
+    for (int b = 0; b < h->B; ++b) st = mpopis::worse_status(st, per_slot[b]);
+    if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
+    else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
+    else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
+    return st;
+}
+
 static int sync_status(mpopis_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
     if (h->h_coop_timeouts && !h->coop_disabled) HIPCHK(h, hipMemcpyAsync(h->h_coop_timeouts, h->d_coop_timeouts, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -94,12 +127,7 @@ static int sync_status(mpopis_handle* h) {
     // a cluster gave up waiting for a partner (its slot was recomputed by the one-workgroup kernel in the same step, so the results are
     // complete): this device cannot keep the clusters co-resident right now -- stop using them for this handle instead of paying the wait again
     if (h->h_coop_timeouts && *h->h_coop_timeouts > 0) h->coop_disabled = true;
-    int st = 0;
-    for (int b = 0; b < h->B; ++b) st = mpopis::worse_status(st, h->h_status[b]);
-    if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
-    else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
-    else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
-    return st;
+    return fold_status(h, h->h_status.data());
 }
 
 // ---- ABI ---------------------------------------------------------------------------------------
@@ -213,6 +241,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     launch_rng_tab_init(h->d_rng_tab, h->stream);
     h->h_status.assign(B, 0);
     if (hipHostMalloc((void**)&h->h_pin, sizeof(double) * B * (h->as + 2)) != hipSuccess) h->h_pin = nullptr;
+    if (hipHostMalloc((void**)&h->h_call, call_box_bytes(B, h->ss, cs, h->as), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h->d_call, h->h_call, 0) != hipSuccess) { if (h->h_call) (void)hipHostFree(h->h_call); h->h_call = nullptr; h->d_call = nullptr; }
     if (hipHostMalloc((void**)&h->h_coop_timeouts, sizeof(int)) != hipSuccess) h->h_coop_timeouts = nullptr; else *h->h_coop_timeouts = 0;
     if (const char* e = getenv("MPOPIS_NO_COOP")) h->coop_disabled = atoi(e) != 0;
     // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
@@ -242,6 +272,7 @@ void mpopis_destroy(mpopis_handle* h) {
     for (auto st : h->xstream) if (st) (void)hipStreamSynchronize(st);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->h_call) (void)hipHostFree(h->h_call);
     if (h->h_coop_timeouts) (void)hipHostFree(h->h_coop_timeouts);
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -527,6 +558,52 @@ int mpopis_policy_step(mpopis_handle* h, const mpopis_noise* noise, double* cont
         if (control) memcpy(control, h->h_pin, sizeof(double) * B * h->as);
         if (iters_run) memcpy(iters_run, h->h_pin + (size_t)B * h->as, sizeof(int) * B);
     }
+    HIPCHK(h, hipGetLastError());
+    return rc;
+}
+
+// control = pol(env) with ONE host wait: the synchronous per-MPC-step call of the reference's harness (src/examples/car_example.jl:203-207,
+// mountaincar_example.jl:150-153).  Same results as set_state + set_U + policy_step + get_U (tests/test_gpu_host_api.py); the small inputs and
+// outputs travel through the handle's device-mapped mailbox, so the stream carries kernels only.
+int mpopis_policy_call(mpopis_handle* h, const double* x, const int32_t* t, const int32_t* done, double* U_inout, const mpopis_noise* noise,
+                       double* control, double* cost, double* weights, int32_t* iters_run) {
+    if (!h) return MPOPIS_ERR_ARG;
+    if (!h->h_call || (noise && noise->Z)) {
+        // injected noise is a parity-test path (megabytes of host data): plain composition of the four calls
+        int rc = 0;
+        if (x || t || done) {
+            if (!x) { h->err = "mpopis_policy_call: t / done without x"; return MPOPIS_ERR_ARG; }
+            if ((rc = mpopis_set_state(h, x, t, done)) != 0) return rc;
+        }
+        if (U_inout && (rc = mpopis_set_U(h, U_inout)) != 0) return rc;
+        rc = mpopis_policy_step(h, noise, control, cost, weights, nullptr, nullptr, iters_run);
+        if (U_inout) { const int r2 = mpopis_get_U(h, U_inout); if (!rc) rc = r2; }
+        return rc;
+    }
+    if ((t || done) && !x) { h->err = "mpopis_policy_call: t / done without x"; return MPOPIS_ERR_ARG; }
+    if (h->env.kind == MPOPIS_ENV_CAR && h->env.track.P == 0) { h->err = "track not set"; return MPOPIS_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int B = h->B, K = h->K, cs = h->cs, as = h->as, ss = h->ss;
+    const CallBox hb = call_box(h->h_call, B, ss, cs, as), db = call_box(h->d_call, B, ss, cs, as);
+    int flags = 0;
+    if (x) { memcpy(hb.x, x, sizeof(double) * B * ss); flags |= 1; }
+    if (U_inout) { memcpy(hb.U, U_inout, sizeof(double) * B * cs); flags |= 2; }
+    if (t) { memcpy(hb.t, t, sizeof(int) * B); flags |= 4; }
+    if (done) { memcpy(hb.done, done, sizeof(int) * B); flags |= 8; }
+    const int nx = B * ss, nu = B * cs, nmax = std::max(std::max(nx, nu), B);
+    if (flags) hipLaunchKernelGGL(k_call_in, dim3((nmax + 255) / 256), dim3(256), 0, h->stream, db, h->d_x, h->d_U, h->d_t, h->d_done, nx, nu, B, flags);
+    int rc = h->policy_step_enqueue(false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_call_out, dim3((std::max(nu, B * as) + 255) / 256), dim3(256), 0, h->stream, db, h->d_control, h->d_U, h->d_status, h->d_iters,
+                       h->coop_disabled ? (const int*)nullptr : h->d_coop_timeouts, B * as, nu, B);
+    if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
+    if (weights) HIPCHK(h, hipMemcpyAsync(weights, h->d_w, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, wait_stream(h->stream));
+    if (*hb.coop > 0) h->coop_disabled = true;
+    if (control) memcpy(control, hb.control, sizeof(double) * B * as);
+    if (U_inout) memcpy(U_inout, hb.Uout, sizeof(double) * B * cs);
+    if (iters_run) memcpy(iters_run, hb.iters, sizeof(int) * B);
+    rc = fold_status(h, hb.status);
     HIPCHK(h, hipGetLastError());
     return rc;
 }

@@ -72,6 +72,10 @@ struct mpopis_handle {
     uint64_t mpc_step = 0;
     std::vector<int> h_status;
     double* h_pin = nullptr;          // pinned staging for the small per-step outputs (control, iters)
+    // mpopis_policy_call mailbox: ONE pinned, device-mapped, coherent host block.  The first kernel of the call reads (x, U, t, done) straight
+    // from it, the last kernel writes (control, rolled U, status, iters, cooperative time-outs) straight into it: no copy commands, one wait.
+    // doubles: in_x[B*ss] in_U[B*cs] out_control[B*as] out_U[B*cs]; then ints: in_t[B] in_done[B] out_status[B] out_iters[B] out_coop[1]
+    double* h_call = nullptr; double* d_call = nullptr;   // host pointer / the same block as the device sees it
     // timing
     bool timing = false, ev_open = false; int timing_mask = ~0;
     // MPOPIS_DEBUG_LAUNCH=1: after every kernel class of a policy step, hipGetLastError + stream sync, so that a failing

@@ -78,6 +78,14 @@ class AbstractPathIntegralPolicy:
 
     def __call__(self, env, Z=None, res_i0=None, res_u=None, return_info=False):
         """control = pol(env)."""
+        if Z is None and not return_info:
+            # the production call: one ABI call, one host wait (mpopis_policy_call); pol.U stays resident and is rolled on the device
+            out = self._eng.policy_call(env.state[None], [env.t], [int(env.done)], None, want_cost=self.params.log)
+            if self.params.log:
+                self.logger.traj_costs = out["cost"][0]
+                self.logger.traj_weights = out["weights"][0]
+                self.logger.trajectories = list(self._eng.get_trajectories()[0])
+            return out["control"][0].copy()
         self._eng.set_state(env.state[None], [env.t], [int(env.done)])
         Zb = None if Z is None else _f64(Z)[None]
         ri = None if res_i0 is None else np.asarray(res_i0)[None]

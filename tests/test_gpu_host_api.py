@@ -212,6 +212,66 @@ def test_plain_c_client_gives_the_same_numbers_as_the_python_mirror(M, tmp_path)
                                                                                            got["iters_run"][0], got["iters_run"][1])
         assert lines[step] == want, (lines[step], want)
     eng.close()
+    # part 2 of the client: the reference harness' order (construct, seed!(pol, seed + k), first pol(env)) through a lazily created handle
+    # and mpopis_policy_call; the program itself checks that two runs repeat bit for bit.  Here: the printed controls equal the four-call
+    # composition (set_state + set_U + policy_step + get_U) on an eagerly created, then seeded handle.
+    assert "harness reproducible 1" in out.stdout
+    hl = [l for l in out.stdout.splitlines() if l.startswith("harness trial ")]
+    assert len(hl) == 6
+    for k in (1, 2):
+        envh = eng_mod.Engine("mountaincar", 0, "gmppi", 1, 1, batch=1, lam=1.0, alpha=1.0)
+        pol = eng_mod.Engine("mountaincar", 0, "cemppi", 64, 15, batch=1, lam=0.1, alpha=1.0, ais_its=4, lam_ais=0.0, elite_threshold=0.8, sigma_est="mle",
+                             cma_sigma=1.0, seed=999, cov=[1.0])
+        pol.seed(777 + k - 1)                                   # seed!(pol, seed + k) on a one-slot handle (slot 0 draws from arg + 1)
+        U = np.zeros((1, 15))
+        for s_ in range(3):
+            x, t, done = envh.get_state()
+            pol.set_state(x, t, done); pol.set_U(U)
+            got = pol.policy_step(None, minimal=True)
+            U = pol.get_U()
+            envh.env_step(got["control"])
+            want = "harness trial %d step %d x %.17g %.17g control %.17g U0 %.17g" % (k, s_, x[0, 0], x[0, 1], got["control"][0, 0], U[0, 0])
+            assert hl[(k - 1) * 3 + s_] == want, (hl[(k - 1) * 3 + s_], want)
+        envh.close(); pol.close()
+    # the round-3 binding logic (a seed issued before the handle exists is dropped, the handle is created with a clock seed) must FAIL this program
+    exe_old = str(tmp_path / "abi_client_old")
+    r = subprocess.run(["gcc", "-std=c99", "-DBINDING_DROPS_EARLY_SEED", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_client.c"),
+                        "-L" + libdir, "-lmpopis_hip", "-Wl,-rpath," + libdir, "-o", exe_old], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    old = subprocess.run([exe_old], capture_output=True, text=True, timeout=120)
+    assert old.returncode == 2 and "not reproducible" in old.stderr, (old.returncode, old.stderr)
+
+
+def test_policy_call_equals_the_four_call_composition(M):
+    """mpopis_policy_call (one host wait, mailbox in pinned mapped memory) against set_state + set_U + policy_step + get_U on a twin handle:
+    controls, rolled U, costs, weights and iters bit-identical over a short closed loop; car env, 3 slots, :μΣaismppi and :cemppi;
+    x = None keeps the resident state; U = None rolls the resident pol.U."""
+    from mpopis_amd import engine as eng_mod
+    for pol, kw in (("μΣaismppi", {}), ("cemppi", dict(sigma_est="ss", elite_threshold=0.8)), ("gmppi", {})):
+        mk = lambda: eng_mod.Engine("car", 1, pol, 256, 20, batch=3, lam=10.0, alpha=1.0, ais_its=3, lam_ais=20.0, cov=[0.0625, 0.1], seed=41, **kw)
+        a, b = mk(), mk()
+        Ua, Ub = np.zeros((3, 40)), np.zeros((3, 40))
+        for step in range(4):
+            x, t, done = b.get_state()
+            x[:, 3] += 0.25 * step                               # the host owns the state: hand over something the resident copy does not hold
+            ra = a.policy_call(x, t, done, Ua, want_cost=True)   # Ua rolled in place
+            b.set_state(x, t, done); b.set_U(Ub)
+            rb = b.policy_step(None)
+            Ub = b.get_U()
+            for k in ("control", "cost", "weights", "iters_run"):
+                assert np.array_equal(ra[k], rb[k]), (pol, step, k)
+            assert np.array_equal(Ua, Ub), (pol, step)
+            assert np.array_equal(a.get_U(), Ub) and np.array_equal(a.get_state()[0], x)
+            b.env_step(rb["control"])
+        # resident forms: no state / no U handed over
+        xa = a.get_state()[0]
+        b.set_state(xa, *a.get_state()[1:])
+        r1 = a.policy_call()
+        r2 = b.policy_step(None, minimal=True)
+        assert np.array_equal(r1["control"], r2["control"]) and np.array_equal(a.get_U(), b.get_U())
+        with pytest.raises(Exception):
+            a.policy_call(None, [0, 0, 0], None)                 # t without x
+        a.close(); b.close()
 
 
 def test_concurrent_handles_with_cooperative_kernels(M):
