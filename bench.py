@@ -50,27 +50,58 @@ def _oracle_noise(cars, Kc, n_iter, step):
     return np.stack([O.philox_normals(20240001, step, n, cs * Kc).reshape(Kc, cs) for n in range(n_iter)])
 
 
-def cpu_port(policy, cars, Kc, Nc, nthreads, budget_s, max_steps=256, **kw):
+def cpu_port(policy, cars, Kc, Nc, nthreads, budget_s, max_steps=256, check_device=None, check_steps=2, **kw):
     """The oracle (C restatement, OpenMP over k like Threads.@threads :269) on this box's host cores: whole pol(env) steps of ONE trial
-    of the given config (the reference's own usage), bounded by budget_s seconds / max_steps steps."""
+    of the given config (the reference's own usage), bounded by budget_s seconds / max_steps steps.
+    check_device: also run the ENGINE (one resident trial, device RNG of the same Philox stream the oracle is fed) in lock step for the
+    first check_steps steps and report the worst deviation of its control / per-rollout cost from the oracle's -- BASELINE.md section 5's
+    "max rel. err vs CPU" column.  The oracle is the checker here; the comparison sits outside every timed bracket."""
+    import numpy as np
     n_iter = 1 if policy == "gmppi" else Nc
     env, pol = _oracle_policy(policy, cars, Kc, Nc, nthreads, **kw)
+    eng, agree = None, None
+    if check_device is not None:
+        from mpopis_amd.engine import Engine
+        eng = Engine("car", cars, policy, Kc, H, batch=1, lam=LAM, alpha=1.0, ais_its=Nc, lam_ais=LAM_AIS, cov=np.tile([0.0625, 0.1], cars),
+                     seed=20240000, device=check_device, **kw)
+        agree = {"control": 0.0, "cost": 0.0, "iters_equal": True, "steps": 0, "chatter_rollouts_set_aside": 0}
     steps, t_total, rollouts = 0, 0.0, 0
-    while True:
-        Z = _oracle_noise(cars, Kc, n_iter, steps)
-        t0 = time.perf_counter()
-        r = pol(env, Z)
-        t_total += time.perf_counter() - t0
-        if r["status"] != 0:
-            break
-        steps += 1
-        rollouts += int(r["iters_run"]) * Kc
-        if t_total >= budget_s or steps >= max_steps:
-            break
-    return {"rollouts_per_s": rollouts / max(t_total, 1e-9), "mpc_steps_per_s": steps / max(t_total, 1e-9), "steps": steps, "seconds": t_total, "threads": nthreads}
+    try:
+        while True:
+            Z = _oracle_noise(cars, Kc, n_iter, steps)
+            if eng is not None and steps < check_steps:
+                eng.set_U(pol.U[None])                    # per-call statement: same state, same pol.U, same draws (closed loops are sensitive maps)
+            t0 = time.perf_counter()
+            r = pol(env, Z)
+            t_total += time.perf_counter() - t0
+            if r["status"] != 0:
+                break
+            if eng is not None and steps < check_steps:
+                got = eng.policy_step(None)
+                agree["iters_equal"] = bool(agree["iters_equal"] and int(got["iters_run"][0]) == int(r["iters_run"]))
+                agree["control"] = max(agree["control"], float(np.max(np.abs(got["control"][0] - r["control"]) / np.maximum(1e-3, np.abs(r["control"])))))
+                rel = np.sort(np.abs(got["cost"][0] - r["cost"]) / (np.abs(r["cost"]) + 1e-9))
+                skip = max(1, Kc // 500)                  # the few standstill-chatter rollouts (sign(Vx), src/envs/car_racing.jl:311; DESIGN.md section 5)
+                agree["cost"] = max(agree["cost"], float(rel[-skip - 1]))
+                agree["chatter_rollouts_set_aside"] += int(np.sum(rel[-skip:] > 1e-7))
+                agree["steps"] += 1
+            steps += 1
+            rollouts += int(r["iters_run"]) * Kc
+            if t_total >= budget_s or steps >= max_steps:
+                break
+    finally:
+        if eng is not None:
+            eng.close()
+    out = {"rollouts_per_s": rollouts / max(t_total, 1e-9), "mpc_steps_per_s": steps / max(t_total, 1e-9), "steps": steps, "seconds": t_total, "threads": nthreads}
+    if agree is not None:
+        agree["what"] = ("engine (1 resident trial, device Philox stream) vs the CPU oracle fed the same stream, %d pol(env) call(s), same state and pol.U per call: "
+                         "control = max |dev - cpu| / max(1e-3, |cpu|); cost = max relative deviation over the K rollouts of the last iteration beyond the K/500 largest "
+                         "(standstill chatter); tolerance of the north star: 1e-5" % agree["steps"])
+        out["max_rel_err_vs_cpu"] = agree
+    return out
 
 
-def cpu_baseline(seconds_target=12.0):
+def cpu_baseline(seconds_target=12.0, check_device=None):
     """The oracle on this box's host cores, headline workload: whole pol(env) steps of ONE trial, bounded to ~10-30 s of CPU work.  The thread
     count is calibrated first (one step each at 8..all cores): on the GPU boxes more OpenMP threads than physical cores available to the
     container make the oracle slower, and the fastest setting is the fair baseline."""
@@ -87,7 +118,7 @@ def cpu_baseline(seconds_target=12.0):
             best_t, best_n = dt, nt
         if dt > 4 * best_t:
             break
-    r = cpu_port("μΣaismppi", CARS, K, N_AIS, best_n, max(2.0, seconds_target - t_cal))
+    r = cpu_port("μΣaismppi", CARS, K, N_AIS, best_n, max(2.0, seconds_target - t_cal), check_device=check_device)
     # BASELINE.md section 4 also asks for the 1-thread figure: one MPC step of the same trial on a single core
     env1, pol1 = _oracle_policy("μΣaismppi", CARS, K, N_AIS, 1)
     t0 = time.perf_counter()
@@ -97,15 +128,79 @@ def cpu_baseline(seconds_target=12.0):
             "value_1thread": N_AIS * K / t_one, "sample_1thread": "1 MPC step of 1 trial (%d rollouts), 1 thread, %.1f s" % (N_AIS * K, t_one),
             "sample": "%d MPC step(s) of 1 trial, same config (%d rollouts), C oracle + OpenMP over k, %.1f s (+%.1f s calibrating the thread count; host reports %d CPUs)"
                       % (r["steps"], r["steps"] * N_AIS * K, r["seconds"], t_cal, ncpu),
-            "mpc_steps_per_s": r["mpc_steps_per_s"]}
+            "mpc_steps_per_s": r["mpc_steps_per_s"], "max_rel_err_vs_cpu": r.get("max_rel_err_vs_cpu")}
 
 
-def cpu_configs(nthreads):
-    """CPU rows of BASELINE.md section 5's table for C2, C3, C4: one trial each (the reference's own usage), bounded samples."""
+def cpu_configs(nthreads, check_device=None):
+    """CPU rows of BASELINE.md section 5's table for C2, C3, C4: one trial each (the reference's own usage), bounded samples; with the
+    engine run in lock step for the agreement column."""
     out = {}
-    out["C2"] = cpu_port("gmppi", 1, 1024, 1, nthreads, 1.0)
-    out["C3"] = cpu_port("cemppi", 1, 150, 10, nthreads, 1.5, sigma_est="ss", elite_threshold=0.8)
-    out["C4"] = cpu_port("cmamppi", 3, 4096, 10, nthreads, 4.0, max_steps=2, elite_threshold=0.8, cma_sigma=0.75)
+    out["C2"] = cpu_port("gmppi", 1, 1024, 1, nthreads, 1.0, check_device=check_device)
+    out["C3"] = cpu_port("cemppi", 1, 150, 10, nthreads, 1.5, check_device=check_device, sigma_est="ss", elite_threshold=0.8)
+    out["C4"] = cpu_port("cmamppi", 3, 4096, 10, nthreads, 4.0, max_steps=2, check_device=check_device, elite_threshold=0.8, cma_sigma=0.75)
+    return out
+
+
+def measure_sync_calls(policy, cars, Kc, Nc, steps, device, frozen=True, **kw):
+    """The reference's own call pattern (src/examples/car_example.jl:203-207): ONE trial, the host owns the env, `act = pol(env)` is a
+    synchronous call per MPC step -- state and pol.U in, control and the rolled pol.U out (mpopis_policy_call: one host wait).  Wall time of
+    that call per MPC step, measured from this Python process (ctypes, pre-bound pointers), in three loops on handles with the same seed:
+      frozen       the same start state every call (what mpopis_bench_policy_steps does: directly comparable with the row's resident ms_per_step;
+                   not for :cmamppi, whose Σ update needs the state to move)
+      closed_loop  env(act) between the calls (mpopis_env_step + mpopis_get_state play the host's env, not timed).  The kernels themselves
+                   take longer at mid-lap states than at the reset state (rollouts that brake to a standstill / leave the anchor's
+                   neighbourhood take the general paths), so this is compared with `resident_closed_loop_ms_per_step`: the same MPC steps
+                   of the same seed run by mpopis_run_trials without any host round trip
+      four_calls   closed loop through the pre-ABI-3 composition set_state + set_U + policy_step + get_U (four waits)"""
+    import ctypes as C
+    import numpy as np
+    from mpopis_amd.engine import Engine
+    cs = 2 * cars * H
+    mk = lambda: Engine("car", cars, policy, Kc, H, batch=1, lam=LAM, alpha=1.0, ais_its=Nc, lam_ais=LAM_AIS, cov=np.tile([0.0625, 0.1], cars),
+                        seed=20240000, device=device, **kw)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    res = {}
+    for mode in (("frozen",) if frozen else ()) + ("closed_loop", "four_calls"):
+        eng = mk()
+        try:
+            x, t, done = eng.get_state()
+            U = np.zeros((1, cs)); ctl = np.zeros((1, 2 * cars)); rew = np.zeros(1)
+            xp, tp, dnp, Up, cp, rp = (x.ctypes.data_as(dp), t.ctypes.data_as(ip), done.ctypes.data_as(ip), U.ctypes.data_as(dp), ctl.ctypes.data_as(dp), rew.ctypes.data_as(dp))
+            L, h = eng.L, eng._h
+            ts, failed = [], None
+            for s_ in range(steps + 3):
+                t0 = time.perf_counter()
+                if mode != "four_calls":
+                    rc = L.mpopis_policy_call(h, xp, tp, dnp, Up, None, cp, None, None, None)
+                else:
+                    rc = L.mpopis_set_state(h, xp, tp, dnp) or L.mpopis_set_U(h, Up) or L.mpopis_policy_step(h, None, cp, None, None, None, None, None) or L.mpopis_get_U(h, Up)
+                dt = time.perf_counter() - t0
+                if rc != 0:                               # :cmamppi closed loops can end in the reference's own PosDefException
+                    failed = int(rc)
+                    break
+                if s_ >= 3:
+                    ts.append(dt * 1e3)
+                if mode != "frozen" and (L.mpopis_env_step(h, cp, rp) != 0 or L.mpopis_get_state(h, xp, tp, dnp) != 0):
+                    break
+            ts.sort()
+            res[mode] = {"median": ts[len(ts) // 2] if ts else None, "mean": sum(ts) / len(ts) if ts else None, "min": ts[0] if ts else None,
+                         "p90": ts[min(len(ts) - 1, int(0.9 * len(ts)))] if ts else None, "steps": len(ts), "stopped_with": failed}
+        finally:
+            eng.close()
+    eng = mk()
+    try:
+        eng.run_trials(num_steps=2, laps=4)               # the same 3 warm-up steps
+        t0 = time.perf_counter()
+        eng.run_trials(num_steps=steps - 1, laps=4)
+        resident = (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        eng.close()
+    out = {"abi_sync_ms_per_step": (res["frozen"] if frozen else res["closed_loop"])["median"],
+           "abi_sync_loop": "frozen start state (comparable with ms_per_step of this row)" if frozen else "closed loop (comparable with this row's closed-loop ms_per_step)",
+           "abi_sync": {k: res[k] for k in res if k != "four_calls"}, "abi_four_call_ms_per_step": res["four_calls"]["median"], "abi_four_calls": res["four_calls"],
+           "resident_closed_loop_ms_per_step": resident,
+           "what": "one trial through the C ABI from this Python process (ctypes, pre-bound pointers): wall ms of the synchronous pol(env) call per MPC step; "
+                   "resident_closed_loop = mpopis_run_trials over steps 3..%d of the same seed (policy step + env step on the device, no host round trip)" % (steps + 2)}
     return out
 
 
@@ -151,7 +246,9 @@ def measure_config(name, policy, cars, Kc, Nc, trials, steps, device, closed_loo
     overlap = sum(per_step.values()) / (ms / steps)
     rps = rollouts / (ms * 1e-3)
     ba = alg_bytes(policy, cs)
-    return {"config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
+    # the reference's own call pattern (one trial, synchronous pol(env) per MPC step through the C ABI), next to the resident figure
+    sync = measure_sync_calls(policy, cars, Kc, Nc, 60 if Kc * Nc * cars < 20000 else 12, device, frozen=not closed_loop, **kw) if trials == 1 else {}
+    return {**sync, "config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
             "loop": "closed loop (mpopis_run_trials)" if closed_loop else "policy steps (mpopis_bench_policy_steps)",
             "kernel_ms_per_step": per_step, "dominant": {"class": dom, "avg_launch_us": tm[dom][0] / tm[dom][1] * 1e3, "share_of_kernel_time": per_step[dom] / sum(per_step.values())},
             "kernel_time_over_step_time": overlap,
@@ -171,6 +268,18 @@ def baseline_configs(device, quick=False):
     for trials in ((1, 8, 32, 64) if not quick else (1,)):
         out.append(measure_config("C4 Car-Racing 3-car :cmamppi K=4096 H=50 N=10", "cmamppi", 3, 4096, 10, trials, 10 // S, device, closed_loop=True, elite_threshold=0.8, cma_sigma=0.75))
     return out
+
+
+def source_sha(files):
+    """sha256 over the named source files (what a committed measurement file is tied to)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_SOURCES = ("mpopis_amd/csrc/kernels_rollout.hip", "mpopis_amd/csrc/car_dynamics.h")     # what profiles/pmc_rollout.json measured
 
 
 def self_launch(n):
@@ -198,9 +307,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--repeats", type=int, default=10, help="extra repetitions of the timed region (after it), for median / min / max")
+    ap.add_argument("--repeats", type=int, default=100, help="extra repetitions of the timed region (after it), for median / min / max")
     ap.add_argument("--no-configs", action="store_true", help="skip the C2/C3/C4 block (BASELINE configs[1..3])")
     ap.add_argument("--quick-configs", action="store_true", help="C2/C3/C4 at one trial and fewer steps only (tests)")
+    ap.add_argument("--no-midlap", action="store_true", help="skip the mid-lap-state variant of the workload (N = 1)")
     ap.add_argument("--multi-stream", action="store_true", help="also time the opt-in four-part schedule (mpopis_set_overlap(h, 4)) after the timed region")
     # development aids for exercising the N > 1 control flow on a 1-GPU box (never used by the driver): all ranks on cuda:0 over gloo.
     # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
@@ -253,8 +363,10 @@ def main():
     eng = Engine("car", CARS, "μΣaismppi", K, H, batch=B, lam=LAM, alpha=1.0, ais_its=N_AIS, lam_ais=LAM_AIS,
                  cov=np.tile([0.0625, 0.1], CARS), seed=20240000 + rank * B, device=local_rank)
 
-    def sync():
-        if dist is not None:
+    def sync(barrier=True):
+        # opening bracket: barrier + device sync.  Closing bracket: device sync only -- the all_reduce(MAX) of the per-rank times that follows
+        # orders the ranks, so no collective's latency is charged to the timed region
+        if dist is not None and barrier:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -325,7 +437,7 @@ def main():
     # summary stats only: per-trial record (control + mean cost) gathered to rank 0 over RCCL
     if dist is not None:
         summary_gather(eng)
-    sync()
+    sync(barrier=False)
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if dist is not None:
@@ -340,7 +452,7 @@ def main():
         eng.bench_policy_steps(args.steps)
         if dist is not None:
             summary_gather(eng)
-        sync()
+        sync(barrier=False)
         tr = torch.tensor([time.perf_counter() - t0r], device=cdev, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(tr, op=dist.ReduceOp.MAX)
@@ -362,6 +474,21 @@ def main():
         eng.timing_enable(False)
         eng.set_overlap(-1)
 
+    # ---- the same workload at mid-lap states (N = 1 only; outside the timed region) -------------------------------------------------
+    # The timed region keeps every trial at the reset state (the synthetic workload of the contract).  In a closed loop the cars are at speed
+    # on curved track sections: more rollouts brake to a standstill or leave their anchor's neighbourhood, and the rollout kernel's general
+    # paths run more often.  100 closed-loop MPC steps of all trials (mpopis_run_trials), then the same policy steps from THOSE states.
+    midlap = None
+    if world == 1 and not args.no_midlap:
+        eng.run_trials(num_steps=99, laps=4)
+        eng.bench_policy_steps(2)
+        eng.timing_enable(2); eng.timing_reset()
+        ms_m, rl_m = eng.bench_policy_steps(args.steps)
+        tm_m = eng.timing_read()
+        eng.timing_enable(False)
+        midlap = {"what": "same workload, every trial started from the state it reached after 100 closed-loop MPC steps (mpopis_run_trials) instead of the reset state",
+                  "ms_per_step": ms_m / args.steps, "value": rl_m / (ms_m * 1e-3), "rollout_avg_launch_us": tm_m["rollout"][0] / max(1, tm_m["rollout"][1]) * 1e3}
+
     # ---- strong scaling: BASELINE configs[4] as written = 64 trials in total, 64/N per GPU (N > 1 only) ------------------
     strong = None
     if world > 1 and TRIALS_PER_GPU % world == 0:
@@ -376,7 +503,7 @@ def main():
         t0s = time.perf_counter()
         _, rl_s = eng_s.bench_policy_steps(args.steps)
         summary_gather(eng_s)
-        sync()
+        sync(barrier=False)
         dts = torch.tensor([time.perf_counter() - t0s], device=cdev, dtype=torch.float64)
         dist.all_reduce(dts, op=dist.ReduceOp.MAX)
         dts = float(dts.item())
@@ -394,16 +521,25 @@ def main():
         ach_gbs = per_launch * BYTES_PER_ROLLOUT / r_avg_s / 1e9
         ach_tf = per_launch * FLOPS_PER_ROLLOUT / r_avg_s / 1e12
         m_ms, m_n = tm_multi["rollout"]
+        # PMC-derived side fields: counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this same command,
+        # tools/profile_round.sh); they come from profiles/pmc_rollout.json, which records the sha of the rollout kernel's sources it measured.
+        # They are emitted only when that sha matches the files of THIS tree -- a stale file yields null + the reason, never old numbers.
         traffic, valu_busy, flops_exec, valu_per_rollout, clock_ghz = None, None, None, None, None
         pj = os.path.join(ROOT, "profiles", "pmc_rollout.json")      # written by tools/pmc_summary.py from separate --pmc passes
+        sha_now = source_sha(PMC_SOURCES)
+        pmc_state = "profiles/pmc_rollout.json missing"
         if os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
-                traffic, valu_busy = pm.get("hbm_bytes_per_rollout") * per_launch, pm.get("valu_busy_frac")
-                flops_exec = pm.get("fp64_flops_per_rollout")
-                valu_per_rollout, clock_ghz = pm.get("valu_insts_per_rollout"), pm.get("effective_clock_ghz")
-            except Exception:
-                traffic = None
+                if pm.get("source_sha") == sha_now:
+                    traffic, valu_busy = pm.get("hbm_bytes_per_rollout") * per_launch, pm.get("valu_busy_frac")
+                    flops_exec = pm.get("fp64_flops_per_rollout")
+                    valu_per_rollout, clock_ghz = pm.get("valu_insts_per_rollout"), pm.get("effective_clock_ghz")
+                    pmc_state = "profiles/pmc_rollout.json matches this tree (source_sha %s over %s)" % (sha_now, " + ".join(PMC_SOURCES))
+                else:
+                    pmc_state = "profiles/pmc_rollout.json is STALE (measured source_sha %s, this tree %s): PMC-derived fields are null" % (pm.get("source_sha"), sha_now)
+            except Exception as ex:                      # noqa: BLE001
+                pmc_state = "profiles/pmc_rollout.json unreadable: %s" % str(ex)[:60]
         srt = sorted(samples)
         med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
         step_bytes = total_rollouts / world * BYTES_PER_ROLLOUT            # per GPU: algorithmic bytes of the whole path in the timed region
@@ -419,7 +555,7 @@ def main():
                         "ms_per_step": {"median": med / args.steps * 1e3, "min": srt[0] / args.steps * 1e3, "max": srt[-1] / args.steps * 1e3},
                         "value": {"median": total_rollouts / med, "max": total_rollouts / srt[0], "min": total_rollouts / srt[-1]}},
             "roofline": {"bound": "fp64_valu", "contract_bound": "hbm", "kernel": "k_rollout_car<1, 4, false, true>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "pmc_source": pmc_state,
                          "frac_definition": "contract formula: whole-path algorithmic bytes per launch (SURVEY 8d: %d B x rollouts per launch) / the dominant kernel's average launch time / 8 TB/s" % BYTES_PER_ROLLOUT,
                          "what_binds": "FP64 VALU issue of the rollout kernel (HBM is at kernel_traffic_frac of peak: nothing is re-read; no MFMA in this kernel)",
                          "step_frac": step_bytes / dt / (HBM_PEAK_GBS * 1e9),
@@ -446,17 +582,23 @@ def main():
                          "note": "fp64_reference_* prices SURVEY 8(d)'s 3.5e5 flop-equivalents of the REFERENCE formulation per rollout; the kernel executes ~4x fewer (transcendental-free sub-step), so this can exceed 1"},
             "kernel_ms_per_step": {k: v[0] / max(1, min(args.steps, 5)) for k, v in tm_all.items() if v[1]},
             "summary_gather": gather_path,
+            "midlap_states": midlap,
         }
         if strong is not None:
             out["strong_scaling"] = strong
         if not args.no_configs and world == 1:
             out["configs"] = baseline_configs(local_rank, quick=args.quick_configs)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(check_device=local_rank)
+            out["max_rel_err_vs_cpu"] = out["cpu_baseline"].pop("max_rel_err_vs_cpu")      # headline config: BASELINE.md section 5's agreement column
             if "configs" in out and not args.quick_configs:
-                cpu = cpu_configs(out["cpu_baseline"]["cores"])                      # CPU rows of the same table, one trial each
+                cpu = cpu_configs(out["cpu_baseline"]["cores"], check_device=local_rank)      # CPU rows of the same table, one trial each
                 for c in out["configs"]:
-                    c["cpu_one_trial"] = cpu[c["config"][:2]]
+                    row = dict(cpu[c["config"][:2]])
+                    c["max_rel_err_vs_cpu"] = row.pop("max_rel_err_vs_cpu", None)
+                    c["cpu_one_trial"] = row
+        if world > 1:
+            out["n1_only"] = "cpu_baseline, max_rel_err_vs_cpu and the configs block (C2/C3/C4, abi_sync_ms_per_step) are measured at N = 1 only (one GPU, rank 0's host cores)"
         print(json.dumps(out, ensure_ascii=False))
     eng.close()
     if dist is not None:

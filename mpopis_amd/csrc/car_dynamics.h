@@ -33,6 +33,21 @@
 #define MP_HD inline
 #endif
 
+// dev builds (tools/path_stats.sh, -DMPOPIS_PATH_STATS): wave-level counts of which path a rollout kernel took -- [0] sub-steps, [1] sub-steps in which
+// some lane took the general sub-step, [2] lanes in it, [3] reward evaluations, [4] evaluations through the general nearest-point search
+#if defined(MPOPIS_PATH_STATS) && defined(__HIPCC__)
+static __device__ unsigned long long g_path_stats[8];
+#endif
+#if defined(MPOPIS_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define MPOPIS_STAT(i, n) do { const unsigned long long ex_ = __builtin_amdgcn_read_exec(); \
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)ex_) - 1) atomicAdd(&g_path_stats[i], (unsigned long long)(n)); } while (0)
+#define MPOPIS_STAT_LANES() __popcll(__builtin_amdgcn_read_exec())
+#endif
+#ifndef MPOPIS_STAT
+#define MPOPIS_STAT(i, n) do { } while (0)
+#define MPOPIS_STAT_LANES() 0
+#endif
+
 namespace mpopis {
 
 constexpr int kCarNParams = 20;
@@ -368,9 +383,11 @@ MP_HD void car_integrate(const CarParams& p, const ActionConsts& k, SteerF&& ste
     double rdt = r * p.ddt, sx = 0.0, sy = 0.0;
     auto substep = [&]() {
         steer(sd, cd);                                                         // delta += dd :301
+        MPOPIS_STAT(0, 1);
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
         if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
+            MPOPIS_STAT(1, 1); MPOPIS_STAT(2, MPOPIS_STAT_LANES());
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
             rdt = r * p.ddt;
             return;
@@ -571,11 +588,13 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
     // rollout kernels (anchor carried, ring table staged): one wave-uniform branch -- every lane on the straight-line path, or the whole
     // wave through the general search (first step of a rollout, a lane far off its anchor, exact ties)
     const bool fast = tk.ring && anchor && ring_candidates(tk.ring, tk.ring_cert, *anchor, x, y, &rel);
+    MPOPIS_STAT(3, 1);
     if (__builtin_expect(tk.ring && anchor && wave_all(fast), 1)) {
         within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
         const int mi = *anchor + rel;
         *anchor = (mi < 0) ? tk.P - 1 : ((mi >= tk.P) ? 0 : mi);
     } else {
+        MPOPIS_STAT(4, 1);
         within = within_track(tk, x, y, &dist, anchor);
     }
     double rew = 0.0;

@@ -29,6 +29,7 @@ static std::string g_create_error;
 
 #include "engine_handle.h"
 #include <chrono>
+#include <atomic>
 
 // ---- tiny utility kernels -----------------------------------------------------------------------
 __global__ void k_fill_i32(int* p, int v, size_t n) { size_t i = blockIdx.x * (size_t)256 + threadIdx.x; if (i < n) p[i] = v; }
@@ -44,27 +45,30 @@ __global__ void k_scaled_copy_f64(const double* s, size_t sstride, const double*
 }
 
 // mpopis_policy_call: the hand-over kernels between the pinned mailbox (device-mapped host memory) and the resident buffers.
-struct CallBox { double *x, *U, *control, *Uout; int *t, *done, *status, *iters, *coop; };
+struct CallBox { double *x, *U, *control, *Uout; int *t, *done, *status, *iters, *coop; volatile int* seq; };
 static CallBox call_box(double* base, int B, int ss, int cs, int as) {
     CallBox m;
     m.x = base; m.U = m.x + (size_t)B * ss; m.control = m.U + (size_t)B * cs; m.Uout = m.control + (size_t)B * as;
-    m.t = (int*)(m.Uout + (size_t)B * cs); m.done = m.t + B; m.status = m.done + B; m.iters = m.status + B; m.coop = m.iters + B;
+    m.t = (int*)(m.Uout + (size_t)B * cs); m.done = m.t + B; m.status = m.done + B; m.iters = m.status + B; m.coop = m.iters + B; m.seq = m.coop + 1;
     return m;
 }
-static size_t call_box_bytes(int B, int ss, int cs, int as) { return sizeof(double) * ((size_t)B * (ss + 2 * cs + as)) + sizeof(int) * ((size_t)4 * B + 2); }
+static size_t call_box_bytes(int B, int ss, int cs, int as) { return sizeof(double) * ((size_t)B * (ss + 2 * cs + as)) + sizeof(int) * ((size_t)4 * B + 4); }
 __global__ void k_call_in(CallBox m, double* x, double* U, int* t, int* done, int nx, int nu, int B, int flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if ((flags & 1) && i < nx) x[i] = m.x[i];
     if ((flags & 2) && i < nu) U[i] = m.U[i];
     if (i < B) { if (flags & 4) t[i] = m.t[i]; if (flags & 8) done[i] = m.done[i]; }
 }
-__global__ void k_call_out(CallBox m, const double* control, const double* U, const int* status, const int* iters, const int* coop, int nc, int nu, int B) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nc) m.control[i] = control[i];
-    if (i < nu) m.Uout[i] = U[i];
-    if (i < B) { m.status[i] = status[i]; m.iters[i] = iters[i]; }
-    if (i == 0) *m.coop = coop ? *coop : 0;
+// ONE workgroup: every thread stores its share and fences at system scope, the workgroup meets, then thread 0 publishes the call's sequence
+// number -- the host may spin on that word instead of going through the runtime's completion signal.
+__global__ void k_call_out(CallBox m, const double* control, const double* U, const int* status, const int* iters, const int* coop, int nc, int nu, int B, int seq) {
+    for (int i = threadIdx.x; i < nc; i += 256) m.control[i] = control[i];
+    for (int i = threadIdx.x; i < nu; i += 256) m.Uout[i] = U[i];
+    for (int i = threadIdx.x; i < B; i += 256) { m.status[i] = status[i]; m.iters[i] = iters[i]; }
+    if (threadIdx.x == 0) *m.coop = coop ? *coop : 0;
     __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *m.seq = seq; __threadfence_system(); }
 }
 
 static void fill_i32(int* p, int v, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n); }
@@ -243,6 +247,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     if (hipHostMalloc((void**)&h->h_pin, sizeof(double) * B * (h->as + 2)) != hipSuccess) h->h_pin = nullptr;
     if (hipHostMalloc((void**)&h->h_call, call_box_bytes(B, h->ss, cs, h->as), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void**)&h->d_call, h->h_call, 0) != hipSuccess) { if (h->h_call) (void)hipHostFree(h->h_call); h->h_call = nullptr; h->d_call = nullptr; }
+    if (h->h_call) memset(h->h_call, 0, call_box_bytes(B, h->ss, cs, h->as));
     if (hipHostMalloc((void**)&h->h_coop_timeouts, sizeof(int)) != hipSuccess) h->h_coop_timeouts = nullptr; else *h->h_coop_timeouts = 0;
     if (const char* e = getenv("MPOPIS_NO_COOP")) h->coop_disabled = atoi(e) != 0;
     // Σ default = I (cov_mat default [1.0], src/mppi_mpopi_policies.jl:42) ; seeds
@@ -594,11 +599,33 @@ int mpopis_policy_call(mpopis_handle* h, const double* x, const int32_t* t, cons
     if (flags) hipLaunchKernelGGL(k_call_in, dim3((nmax + 255) / 256), dim3(256), 0, h->stream, db, h->d_x, h->d_U, h->d_t, h->d_done, nx, nu, B, flags);
     int rc = h->policy_step_enqueue(false);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_call_out, dim3((std::max(nu, B * as) + 255) / 256), dim3(256), 0, h->stream, db, h->d_control, h->d_U, h->d_status, h->d_iters,
-                       h->coop_disabled ? (const int*)nullptr : h->d_coop_timeouts, B * as, nu, B);
+    const int seq = ++h->call_seq;
+    hipLaunchKernelGGL(k_call_out, dim3(1), dim3(256), 0, h->stream, db, h->d_control, h->d_U, h->d_status, h->d_iters,
+                       h->coop_disabled ? (const int*)nullptr : h->d_coop_timeouts, B * as, nu, B, seq);
     if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
     if (weights) HIPCHK(h, hipMemcpyAsync(weights, h->d_w, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, wait_stream(h->stream));
+    // Host wait.  Without bulk outputs everything the caller gets back sits in the mailbox, published by the sequence word: spin on that word
+    // (coherent host memory; the store lands ~1-2 us after the kernel issues it) and leave the stream's completion signal alone -- the next call
+    // is ordered behind this one by the stream anyway.  Every ~20 us the stream is queried so that a fault ends the wait; after 3 ms: block.
+    static const int env_wait = [] { const char* e = getenv("MPOPIS_CALL_WAIT"); return e ? atoi(e) : 1; }();      // 0: runtime wait only (A/B)
+    if (env_wait && !cost && !weights) {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto tq = t0;
+        for (;;) {
+            if (*hb.seq == seq) break;
+            const auto now = std::chrono::steady_clock::now();
+            if (now - tq > std::chrono::microseconds(20)) {
+                tq = now;
+                const hipError_t e = hipStreamQuery(h->stream);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) HIPCHK(h, e);
+                if (now - t0 > std::chrono::milliseconds(3)) { HIPCHK(h, hipStreamSynchronize(h->stream)); break; }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIPCHK(h, wait_stream(h->stream));
+    }
     if (*hb.coop > 0) h->coop_disabled = true;
     if (control) memcpy(control, hb.control, sizeof(double) * B * as);
     if (U_inout) memcpy(U_inout, hb.Uout, sizeof(double) * B * cs);

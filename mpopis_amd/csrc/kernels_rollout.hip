@@ -55,6 +55,13 @@ inline size_t track_lds_bytes(int P, int W, bool all) {
 __device__ unsigned long long g_roll_prof[3 * 8192];
 extern "C" int mpopis_debug_roll_prof(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_roll_prof), sizeof(g_roll_prof)); }
 #endif
+#ifdef MPOPIS_PATH_STATS
+extern "C" int mpopis_debug_path_stats(unsigned long long* out, int reset) {      // dev build: read (and optionally clear) the path counters of car_dynamics.h
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_path_stats), sizeof(g_path_stats));
+    if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z); }
+    return rc;
+}
+#endif
 template <int NC, int SPB, bool LOG, bool TLDS>
 __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per_eu(4, 4))) k_rollout_car(RolloutArgs a) {
     static_assert(NC == 1, "multi-car envs run k_rollout_cars");

@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc passes (gpurun_out/pmc_r01/*/pmc_counter_collection.csv) per kernel:
-mean counter value per dispatch and mean duration.  Writes profiles/r03_pmc_summary.csv and
+mean counter value per dispatch and mean duration.  Writes profiles/r04_pmc_summary.csv and
 profiles/pmc_rollout.json (HBM bytes per launch of the rollout kernel, used by bench.py)."""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
@@ -21,7 +21,7 @@ for k in sorted(acc, key=lambda k: -sum(dur[k])):
         row[c] = sum(v) / len(v) if v else ""
     rows.append(row)
 os.makedirs("profiles", exist_ok=True)
-with open("profiles/r03_pmc_summary.csv", "w", newline="") as fo:
+with open("profiles/r04_pmc_summary.csv", "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=["kernel", "dispatches_per_pass", "avg_us"] + names)
     w.writeheader()
     w.writerows(rows)
@@ -45,7 +45,10 @@ if ro:
         pass
     known_read = B * cs * K * 8
     fetch_kib, write_kib = r.get("FETCH_SIZE") or 0.0, r.get("WRITE_SIZE") or 0.0
-    out = {"kernel": r["kernel"], "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
+    sha = hashlib.sha256()
+    for f in ("mpopis_amd/csrc/kernels_rollout.hip", "mpopis_amd/csrc/car_dynamics.h"):      # = bench.py PMC_SOURCES: ties this file to the kernel sources it measured
+        sha.update(open(f, "rb").read())
+    out = {"source_sha": sha.hexdigest()[:16], "kernel": r["kernel"], "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
            "known_read_bytes_per_launch": known_read, "fetch_raw_bytes": fetch_kib * 1024,
            "fetch_calibration_ratio_known_over_raw": known_read / (fetch_kib * 1024) if fetch_kib else None,
            "trials_per_launch": B, "hbm_bytes_per_launch": 2 * fetch_kib * 1024 + write_kib * 1024,

@@ -21,5 +21,5 @@ done
 ls "$O"/pmc/*/ | head -20
 # summaries on the box (gpurun merges at most 64 MiB back): per-kernel PMC table + pmc_rollout.json next to the raw passes, then drop the per-dispatch dumps
 cd "$R" && python tools/pmc_summary.py "$O/pmc" > "$O/pmc_summary.log" 2>&1
-cp "$R"/profiles/r03_pmc_summary.csv "$R"/profiles/pmc_rollout.json "$O"/ 2>/dev/null
+cp "$R"/profiles/r04_pmc_summary.csv "$R"/profiles/pmc_rollout.json "$O"/ 2>/dev/null
 rm -f "$O"/pmc/*/pmc_counter_collection.csv "$O"/pmc/*/pmc_kernel_trace.csv "$O"/prof/*kernel_trace.csv
