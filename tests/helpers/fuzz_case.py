@@ -1,0 +1,81 @@
+"""One engine-vs-oracle parity case of the randomised sweep (test infrastructure: uses the oracle).  Shared by tests/dev/fuzz_parity.py (the
+open-ended campaign) and tests/test_gpu_fuzz_slice.py (the fixed-seed slice that runs in the GPU suite).
+A few costs per case may differ beyond 1e-7 without being a bug: rollouts that brake to a standstill chatter; a case
+allows ncars*K/200 of them per slot as long as control and U agree to 1e-6 (the committed shape tests identify those rollouts from the
+oracle's own trajectory instead)."""
+import numpy as np
+
+
+def tag_of(c):
+    return "%s cars=%d K=%d T=%d N=%d B=%d split=%d est=%s rng=%s seed=%d" % (c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"], c["split"], c["est"],
+                                                                                "dev" if c["device_rng"] else "inj", c["seed"])
+
+
+def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
+    """c: dict(kind, ncars, K, T, N, B, split, est, device_rng, seed).  Returns (status, messages): status in {"ok", "fail", "refused"}."""
+    kind, ncars, K, T, N, B = c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"]
+    est, device_rng, seed = c["est"], c["device_rng"], c["seed"]
+    cs = 2 * ncars * T
+    cov = np.tile([0.0625, 0.1], ncars)
+    tag = tag_of(c)
+    try:
+        eng = Engine("car", ncars, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, sigma_est=est, cma_sigma=0.75,
+                     cov=cov, track=track, seed=seed)
+    except MPOPISError as e:
+        return "refused", ["create refused: %s %s" % (tag, e)]
+    msgs = []
+    try:
+        eng.set_overlap(c["split"])
+        envs, pols = [], []
+        for b in range(B):
+            e = O.OracleEnv("car", ncars, track=track)
+            for _ in range(int(rng.integers(0, 30))):
+                e.step(np.clip(np.tile([0.05, 0.5], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
+            envs.append(e)
+            pols.append(O.OraclePolicy(kind, e, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0, elite_threshold=0.8,
+                                       sigma_est=est, cma_sigma=0.75, nthreads=oracle_threads))
+        eng.set_state(np.stack([e.state for e in envs]))
+        for step in range(steps):
+            if kind == "mppi":
+                Z = rng.standard_normal((B, T, K, 2 * ncars))
+            elif device_rng:
+                Z = np.stack([np.stack([O.philox_normals(seed + b + 1, step, n, cs * K).reshape(K, cs) for n in range(N)]) for b in range(B)])
+            else:
+                Z = rng.standard_normal((B, N, K, cs))
+            if device_rng:
+                dd = [[O.philox_resample_draws(seed + b + 1, step, n | 0x80000000, K) for n in range(max(N - 1, 1))] for b in range(B)]
+                di = np.array([[d[0] for d in row] for row in dd], dtype=np.int32)
+                du = np.array([[d[1] for d in row] for row in dd])
+            else:
+                di = rng.integers(0, K, (B, max(N - 1, 1), K)).astype(np.int32)
+                du = rng.random((B, max(N - 1, 1), K))
+            refs = [pols[b](envs[b], Z[b], di[b], du[b]) for b in range(B)]
+            worst = min(r["status"] for r in refs)
+            try:
+                got = eng.policy_step(None if device_rng else Z, None if device_rng else di, None if device_rng else du)
+            except MPOPISError as e:
+                if e.code != worst:
+                    msgs.append("FAIL status %s step %d engine %d oracle %d" % (tag, step, e.code, worst))
+                break
+            if worst:
+                msgs.append("FAIL status %s engine ok, oracle %d" % (tag, worst))
+                break
+            U = eng.get_U()
+            for b in range(B):
+                r = refs[b]
+                rel = np.abs(got["cost"][b] - r["cost"]) / (np.abs(r["cost"]) + 1e-9)
+                nbad = int((rel > 1e-7).sum())
+                ea = float(np.abs(got["control"][b] - r["control"]).max())
+                eu = float(np.abs(U[b] - pols[b].U).max())
+                idx_ok = True
+                if kind == "pmcmppi" and r["iters_run"] > 1:
+                    n_it = r["iters_run"]
+                    idx_ok = bool(np.array_equal(got["res_idx0"][b][:n_it - 1], r["res_idx0"][:n_it - 1]))      # resampling indices: bit-exact
+                if got["iters_run"][b] != r["iters_run"] or nbad > max(2, ncars * K // 200) or ea > 1e-6 or eu > 1e-6 or not idx_ok:
+                    msgs.append("FAIL %s step %d slot %d iters %d %d cost-bad %d max rel %.2e ctrl %.2e U %.2e idx %s" % (
+                        tag, step, b, got["iters_run"][b], r["iters_run"], nbad, rel.max(), ea, eu, idx_ok))
+            if msgs:
+                break
+    finally:
+        eng.close()
+    return ("fail" if msgs else "ok"), msgs

@@ -1,0 +1,69 @@
+"""A fixed-seed slice of the randomised parity sweep (tests/dev/fuzz_parity.py) inside the GPU suite: 72 cases, engine through the C ABI against
+the CPU oracle, laid out so that every policy meets 1-4 cars, batches on both sides of the kernel-selection thresholds (B in {1, 7, 48, 64}:
+one-workgroup vs cooperative Cholesky / Lanczos, two-wave vs one-wave rollouts, rank sort vs bitonic sort, row vs pair-list scatter, fused vs
+two-kernel sampler at cs > 128), both noise sources (injected normals / device Philox stream restated by the oracle) and both schedules (one
+stream / four part-chains).  Tolerances as in the sweep: costs 1e-7 relative (beyond the few standstill-chatter rollouts), control and pol.U
+1e-6, iteration counts and resampling indices exact."""
+import time
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["gmppi", "imppi", "muaismppi", "musigmaaismppi", "cemppi", "pmcmppi", "cmamppi", "mppi"]
+BATCHES = [1, 7, 48, 64]
+ESTS = ["mle", "ss", "lw", "rblw", "oas"]
+
+
+def cases():
+    rng = np.random.default_rng(4242)
+    out = []
+    for i in range(72):
+        kind = KINDS[i % 8]
+        rnd = i // 8                                                # 9 rounds over the 8 policies
+        ncars = 1 + (i // 8 + i % 8) % 4                            # every policy meets 1, 2, 3, 4 cars (twice)
+        B = BATCHES[(i // 8 + 2 * (i % 8)) % 4]
+        big = B >= 48
+        T = int(rng.choice([5, 10, 16] if big else [3, 16, 25, 50]))
+        K = int(rng.choice([64, 150, 256] if big else [17, 65, 256, 700, 1024]))
+        if rnd == 8:                                                # last round: the BASELINE horizon at small batches, large control spaces
+            B, T, K = BATCHES[i % 2], 50, int(rng.choice([256, 1024]))
+        N = 1 if kind in ("gmppi", "mppi") else int(rng.integers(2, 5))
+        device_rng = (rnd + i) % 2 == 1 and kind != "mppi"
+        split = 4 if (rnd // 2 + i) % 2 == 1 and B > 1 else 0
+        est = ESTS[rnd % 5] if kind == "cemppi" else "mle"
+        if kind == "cmamppi" and 2 * ncars * T * round(0.2 * K) < K:
+            K = 64
+        out.append(dict(kind=kind, ncars=ncars, K=K, T=T, N=N, B=B, split=split, est=est, device_rng=device_rng, seed=int(rng.integers(1, 2 ** 31))))
+    return out
+
+
+def test_case_table_covers_the_axes():
+    cs = cases()
+    assert len(cs) == 72
+    for kind in KINDS:
+        mine = [c for c in cs if c["kind"] == kind]
+        assert {c["ncars"] for c in mine} == {1, 2, 3, 4}, kind
+        assert {c["B"] for c in mine} == {1, 7, 48, 64}, kind
+        if kind != "mppi":
+            assert {c["device_rng"] for c in mine} == {True, False}, kind
+        assert {c["split"] for c in mine} == {0, 4}, kind
+    assert {c["est"] for c in cs if c["kind"] == "cemppi"} == set(ESTS)
+
+
+def test_fuzz_slice_against_the_oracle(oracle, track):
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    from mpopis_amd._lib import MPOPISError
+    from tests.helpers.fuzz_case import run_case, tag_of
+    rng = np.random.default_rng(777)
+    t0 = time.time()
+    failed, ran = [], 0
+    for c in cases():
+        st, msgs = run_case(oracle, Engine, MPOPISError, track, c, rng, steps=2 if c["B"] < 48 else 1, oracle_threads=16)
+        assert st != "refused", msgs
+        ran += 1
+        failed += msgs
+    print("\n[fuzz slice] %d cases in %.0f s, %d failure message(s)" % (ran, time.time() - t0, len(failed)))
+    assert not failed, failed[:8]
