@@ -105,7 +105,7 @@ constexpr int kTrackNbrW = 16;
 #include <vector>
 namespace mpopis {
 // host: ring table (see Track::ring) and certification radii from the neighbour table
-inline void build_track_ring(int P, const double* x, const double* y, const double* w, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert);
+inline void build_track_ring(int P, const double* x, const double* y, const double* w, const double* n2, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert);
 // host: neighbour tables of the anchored nearest-point search (row stride W + 1, see Track) for P points; W = min(kTrackNbrW, P)
 inline void build_track_tables(int P, const double* x, const double* y, std::vector<double>& nd, std::vector<int>& ni) {
     const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
@@ -122,20 +122,27 @@ inline void build_track_tables(int P, const double* x, const double* y, std::vec
         nd[(size_t)i * S + W] = r2 * (1.0 - 1e-9);
     }
 }
-inline void build_track_ring(int P, const double* x, const double* y, const double* w, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert) {
+// n2[i] = |q_i|^2 exactly as the caller uploads it for the general search (one computation, copied: ring_candidates and within_track must
+// see bit-identical distances, or a near-tie could resolve differently depending on the path a wave took)
+inline void build_track_ring(int P, const double* x, const double* y, const double* w, const double* n2, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert) {
     const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
     ring.assign((size_t)(P + 4) * 4, 0.0); cert.assign((size_t)P, 0.0);
     for (int e = -2; e <= P + 1; ++e) {
         const int i = ((e % P) + P) % P;
         double* o = ring.data() + (size_t)(e + 2) * 4;
-        o[0] = x[i]; o[1] = y[i]; o[2] = x[i] * x[i] + y[i] * y[i]; o[3] = w[i];
+        o[0] = x[i]; o[1] = y[i]; o[2] = n2[i]; o[3] = w[i];
     }
     for (int i = 0; i < P; ++i) cert[i] = nd[(size_t)i * S + W];
 }
 
-// Rounding discipline of everything below: the compiler may NOT contract a*b + c on its own here (hipcc's default, -ffp-contract=fast, decides
-// per inlining context -- the same source then rounds differently in two kernels, and the wave-specialised rollout kernels, which evaluate parts of
-// a model step in different waves, would stop agreeing bit for bit with the one-wave kernel).  Every fused multiply-add is written as fma().
+// Rounding discipline of everything below: NO implicit a*b + c.  hipcc's default (-ffp-contract=fast, which this library is built with) lets the
+// BACKEND fuse a multiply into a dependent add wherever it finds one, per inlining context and whatever pragma is in force -- the same source
+// would then round differently in two kernels, and the wave-specialised rollout kernels, which evaluate parts of a model step in different
+// waves, would stop agreeing bit for bit with the one-wave kernel.  So the model code leaves the compiler nothing to fuse: every fused
+// multiply-add is written as fma(), every product that feeds an add or subtract unfused in the reference is kept away from it by being an
+// fma operand already.  tools/check_contract.sh verifies it: the rollout kernels compile to the same instruction stream under
+// -ffp-contract=fast and =off outside inlined libm code (sin / cos / fmod of the cold paths).  The pragma below makes the same statement
+// for front ends that honour it (=on / =off builds, the host shim).
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -308,7 +315,7 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     // :322-328 with the same δt-folded constants as the hot path (k_rf = δt l_f/Izz, k_rr = δt l_r/Izz, k_v = δt/m)
     const double flat = fma(fyf, cd, fxf * sd), flon = fma(fxf, cd, -(fyf * sd)), rd = r * p.ddt;
     const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));
-    const double Vx1 = fma(p.k_v, flon + (fxr - fx_aero), fma(rd, Vy, Vx));
+    const double Vx1 = fma(p.k_v, flon + fma(1 - lam, fx, -fx_aero), fma(rd, Vy, Vx));      // (fxr - fx_aero with fxr = (1-λ) fx: written as the fma it is)
     r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));
     Vx = Vx1; Vy = Vy1;
     double dpsi = r * p.ddt;
@@ -340,7 +347,7 @@ MP_HD ActionConsts car_action_consts(const CarParams& p, double a1) {
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
     k.pedal = pedal; k.fxf = fxf;
-    k.fxr0 = fxr - p.CD0;                                      // rear drive force minus the constant part of the drag (:308)
+    k.fxr0 = fma(1 - lam, fx, -p.CD0);                         // rear drive force minus the constant part of the drag (:308); explicit: (1-λ) fx - CD0 is a*b + c
     k.kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);
     k.kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
     return k;
@@ -669,7 +676,7 @@ MP_HD void cp_step(const CpParams& p, double* s, int* t, int* done, double a) {
 
 MP_HD double cp_reward(int done) { return done ? 0.0 : 1.0; }
 #if defined(__clang__)
-#pragma clang fp contract(fast)
+#pragma STDC FP_CONTRACT DEFAULT      // back to the translation unit's own setting (whatever -ffp-contract says), not a hard-coded mode
 #endif
 
 }  // namespace mpopis

@@ -96,6 +96,21 @@ __host__ __device__ __forceinline__ double cost_unkey(unsigned long long k) {
     return v;
 }
 
+// Per-slot error codes merge by PRECEDENCE, on the device like on the host (include/mpopis.h: HIP > ACTION > NOT_PD > NUMERIC -- the codes of
+// ABI version 1 keep their order and the newer MPOPIS_ERR_NUMERIC never hides one of them).  Every kernel that reports into status[b] goes
+// through status_raise: a plain atomicMin would let an earlier NUMERIC (-5) mask a later NOT_PD (-2) / ACTION (-3) of the same slot.
+__host__ __device__ __forceinline__ int status_rank(int c) {
+    return c == MPOPIS_ERR_HIP ? 4 : c == MPOPIS_ERR_ACTION ? 3 : c == MPOPIS_ERR_NOT_PD ? 2 : c == MPOPIS_ERR_NUMERIC ? 1 : c < 0 ? 5 : 0;
+}
+__device__ __forceinline__ void status_raise(int* p, int code) {
+    int cur = *p;
+    while (status_rank(code) > status_rank(cur)) {
+        const int seen = atomicCAS(p, cur, code);
+        if (seen == cur) break;
+        cur = seen;
+    }
+}
+
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
 void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s);
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,

@@ -323,7 +323,7 @@ int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const d
     HIPCHK(h, hipMemcpyAsync(dnd, nd.data(), sizeof(double) * nd.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(dni, ni.data(), sizeof(int) * ni.size(), hipMemcpyHostToDevice, h->stream));
     std::vector<double> ring, cert;
-    build_track_ring(P, x, y, w, nd, ring, cert);
+    build_track_ring(P, x, y, w, n2.data(), nd, ring, cert);
     double* dring = nullptr;
     if (dalloc(h, &dring, ring.size() + cert.size())) return MPOPIS_ERR_HIP;
     HIPCHK(h, hipMemcpyAsync(dring, ring.data(), sizeof(double) * ring.size(), hipMemcpyHostToDevice, h->stream));

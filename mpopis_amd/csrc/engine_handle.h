@@ -101,7 +101,7 @@ struct mpopis_handle {
 namespace mpopis {
 // Error precedence when several slots (or several kernels of one slot) failed in one call: HIP (-4) > ACTION (-3) > NOT_PD (-2) > NUMERIC (-5),
 // i.e. the numeric minimum among the codes of ABI version 1, which the newer MPOPIS_ERR_NUMERIC never hides (include/mpopis.h).
-inline int status_rank(int c) { return c == MPOPIS_ERR_HIP ? 4 : c == MPOPIS_ERR_ACTION ? 3 : c == MPOPIS_ERR_NOT_PD ? 2 : c == MPOPIS_ERR_NUMERIC ? 1 : c < 0 ? 5 : 0; }
+// (status_rank lives in engine.h: the device-side writers merge by the same rule, status_raise)
 inline int worse_status(int a, int b) { return status_rank(b) > status_rank(a) ? b : a; }
 void launch_scale_rows(double* Z, const double* dsc, int B, int cs, int K, hipStream_t s);
 inline void launch_mppi_Z_in(const double* src, double* dst, int B, int T, int K, int as, hipStream_t s) { launch_transpose_in(src, dst, B * T, as, K, s); }

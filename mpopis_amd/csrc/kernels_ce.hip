@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(kCeThreads) k_ce_cov_small(const double* __res
         __shared__ double eb_red[kCeThreads / 64];
         __shared__ int sh_broke;
         const int i = threadIdx.x;
-        const double ci = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+        const double cr = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+        const double ci = (cr != cr) ? INFINITY : cr;            // NaN ranks like +inf: unique ranks, no stale order[] entries (see k_sortperm_rank)
         if (i < kCeSortMax) { c[i] = ci; sc[i] = INFINITY; }
         if (i == 0) sh_broke = 0;
         __syncthreads();
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(kCeThreads) k_ce_cov_small(const double* __res
                         ((c3 < ci) || (c3 == ci && j + 3 < i));
             }
             for (int j = K4; j < K; ++j) rank += ((c[j] < ci) || (c[j] == ci && j < i));
-            order[(size_t)b * K + rank] = i; sc[rank] = ci;
+            order[(size_t)b * K + rank] = i; sc[rank] = cr;
             if (rank < m) sh_idx[rank] = i;
         }
         __syncthreads();

@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     if (!(nrm_b > 0.0) || !(fro > 0.0)) {                             // δw = 0 -> y = 0; NaN input / unusable trace -> numeric error
         if (writer) {
             for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-            if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) atomicCAS(&status[b], 0, MPOPIS_ERR_NUMERIC); }      // never hides an earlier error of the slot
+            if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) status_raise(&status[b], MPOPIS_ERR_NUMERIC); }      // never hides an earlier error of the slot
         }
         return;
     }
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             if (!invsqrt_quad_node(mlo, Mhi, lane, 64, &q_shift, &q_weight)) {       // uniform: depends on mlo / Mhi only
                 if (writer) {
                     for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-                    if (tid == 0) { msteps[b] = 0; atomicCAS(&status[b], 0, MPOPIS_ERR_NUMERIC); }
+                    if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
                 }
                 return;
             }

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
         __syncthreads();
     }
     if (failed) {
-        if (tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+        if (tid == 0) { if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
         return;
     }
     for (int j = wv; j < n; j += NW)
@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
         __threadfence_block();
         __syncthreads();
     }
-    if (failed && tid == 0) { if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+    if (failed && tid == 0) { if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
         PROF_MARK(g, c > 0 ? c - 1 : 31, 5);
         if (sh_fail) {
             if (tid == 0) {
-                if (status) atomicMin(&status[b], MPOPIS_ERR_NOT_PD);
+                if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD);
                 if (active) active[b] = 0;
                 for (int jj = c; jj < npan; ++jj) __hip_atomic_store(&fl[jj], ok_val + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

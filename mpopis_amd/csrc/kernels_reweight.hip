@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cos
             t = block_reduce<false>(t, sh);
             if (threadIdx.x == 0) wsum[b] = t;
         }
-        if (bad && status) atomicMin(&status[b], MPOPIS_ERR_ACTION);
+        if (bad && status) status_raise(&status[b], MPOPIS_ERR_ACTION);
         return;
     }
     for (int k = threadIdx.x; k < K; k += blockDim.x) { const double v = c[k]; m = fmin(m, v); bad |= !(fabs(v) < INFINITY); }
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(1024) k_weights(const double* __restrict__ cos
         t = block_reduce<false>(t, sh);
         if (threadIdx.x == 0) wsum[b] = t;
     }
-    if (bad && status) atomicMin(&status[b], MPOPIS_ERR_ACTION);               // non-finite cost <=> NaN action (car_racing.jl:239)
+    if (bad && status) status_raise(&status[b], MPOPIS_ERR_ACTION);               // non-finite cost <=> NaN action (car_racing.jl:239)
 }
 
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active, int* status, hipStream_t s, double* wsum) {
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
     if (env.kind != MPOPIS_ENV_CAR) {
         if (c == 0) {
             const double a = action[b];
-            if (!(a >= env.lo[0] && a <= env.hi[0])) { if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION); }
+            if (!(a >= env.lo[0] && a <= env.hi[0])) { if (status) status_raise(&status[b], MPOPIS_ERR_ACTION); }
             int tt = t[b], dd = done[b];
             simple_env_step(env, x + (size_t)b * env.ss, &tt, &dd, a);
             t[b] = tt; done[b] = dd;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(64) k_env_step(EnvDesc env, double* x, int* t,
     if (c < NC) {
         const double a0 = action[(size_t)b * 2 * NC + 2 * c], a1 = action[(size_t)b * 2 * NC + 2 * c + 1];
         if (NC == 1 && !(a0 >= env.lo[0] && a0 <= env.hi[0] && a1 >= env.lo[1] && a1 <= env.hi[1])) {
-            if (status) atomicMin(&status[b], MPOPIS_ERR_ACTION);                // car_racing.jl:239
+            if (status) status_raise(&status[b], MPOPIS_ERR_ACTION);                // car_racing.jl:239
         }
         CarState s;
         car_state_from8(s, xb + 8 * c);

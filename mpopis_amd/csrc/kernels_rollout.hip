@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
         if (lane == 0) atomicMin(&a.cmin[b], key);
-        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
+        if (valid && !(fabs(total) < INFINITY) && a.status) status_raise(&a.status[b], MPOPIS_ERR_ACTION);   // non-finite cost <=> NaN action (car_racing.jl:239)
     }
 #ifdef MPOPIS_ROLL_PROF
     if (lane == 0) {
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
         if (lane == 0) atomicMin(&a.cmin[b], key);
-        if (valid && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
+        if (valid && !(fabs(total) < INFINITY) && a.status) status_raise(&a.status[b], MPOPIS_ERR_ACTION);
     }
 }
 
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
         if (lane == 0) atomicMin(&a.cmin[b], key);
-        if (writer && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
+        if (writer && !(fabs(total) < INFINITY) && a.status) status_raise(&a.status[b], MPOPIS_ERR_ACTION);
     }
 }
 
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(key, o, 64); key = (t < key) ? t : key; }
         if (lane == 0) atomicMin(&a.cmin[b], key);
-        if (writer && !(fabs(total) < INFINITY) && a.status) atomicMin(&a.status[b], MPOPIS_ERR_ACTION);
+        if (writer && !(fabs(total) < INFINITY) && a.status) status_raise(&a.status[b], MPOPIS_ERR_ACTION);
     }
 }
 
@@ -483,11 +483,14 @@ void launch_step_begin(int* status, int* active, const int* alive, int* iters, c
     hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin);
 }
 
+// Dynamic LDS a rollout kernel may request without raising its limit: the default 64 KB minus the kernels' STATIC LDS (two-wave kernels:
+// mailbox 4 KB + control-cost column 0.5 KB + flags + per-car bounds, ~4.7 KB).  Beyond it the limit is raised (96 KB) before the launch.
+constexpr size_t kRolloutDynLdsDefault = 56 * 1024;
 // one `seen` mask per kernel (non-type template parameter): large tracks need the dynamic-LDS limit raised, per device
 template <void (*KERNEL)(RolloutArgs)>
 static void launch_rollout_kernel(dim3 grid, int block, size_t lds, hipStream_t st, const RolloutArgs& a) {
     static std::atomic<unsigned long long> seen{0};
-    if (lds > 60 * 1024) ensure_dyn_lds((const void*)KERNEL, 96 * 1024, seen);
+    if (lds > kRolloutDynLdsDefault) ensure_dyn_lds((const void*)KERNEL, 96 * 1024, seen);
     hipLaunchKernelGGL(KERNEL, grid, dim3(block), lds, st, a);
 }
 
@@ -503,7 +506,7 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     const int P = a.env.track.P, W = a.env.track.nbrw;
     // every table in LDS when that fits the default 64 KB (all bundled tracks: 48-60 points); larger tracks (Track(infile; sample_factor = 1):
     // ~1000 points) stage the ring table only (<= 82 KB at the 2048-point limit: the kernels' dynamic-LDS limit is raised to 96 KB once)
-    const bool tl = track_lds_bytes(P, W, true) <= 60 * 1024;
+    const bool tl = track_lds_bytes(P, W, true) <= kRolloutDynLdsDefault;      // (static LDS of the two-wave kernels counted: P = 221, 222 used to total 65.7-66 KB without the limit being raised)
     const size_t lds = track_lds_bytes(P, W, tl);
     // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 waves share the LDS tables
     const bool wide = a.K >= 1024;

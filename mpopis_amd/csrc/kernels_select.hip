@@ -134,7 +134,11 @@ __global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict_
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     const int i = threadIdx.x;
-    const double ci = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+    const double cr = (i < K) ? cost[(size_t)b * K + i] : INFINITY;
+    // the order is (cost, index) with NaN placed like +inf (Julia's isless sorts NaN last): compared as raw doubles every NaN entry would get
+    // rank 0, ranks would repeat and order[] would keep stale indices (the slot is already flagged MPOPIS_ERR_ACTION by the rollout, but the
+    // CE / CMA update behind this sort still gathers through order[] before the host sees the error)
+    const double ci = (cr != cr) ? INFINITY : cr;
     c[i] = ci;
     __syncthreads();
     int rank = 0;
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict_
     }
     for (int j = K4; j < Kr; ++j) rank += ((c[j] < ci) || (c[j] == ci && j < i));
     __syncthreads();
-    if (i < K) { order[(size_t)b * K + rank] = i; sc[rank] = ci; }
+    if (i < K) { order[(size_t)b * K + rank] = i; sc[rank] = cr; }
     __syncthreads();
     elite_break_tail(sc, m_elite, active, b);
 }
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(256) k_sortperm_rank_multi(const double* __res
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     const int tid = threadIdx.x, el = tid & (kRmE - 1), js = tid >> 4;
-    for (int j = tid; j < K; j += 256) c_l[j] = cost[(size_t)b * K + j];
+    for (int j = tid; j < K; j += 256) { const double v = cost[(size_t)b * K + j]; c_l[j] = (v != v) ? INFINITY : v; }      // NaN ranks like +inf (see k_sortperm_rank)
     if (tid < kRmE) sh_rank[tid] = 0;
     __syncthreads();
     const int e = blockIdx.x * kRmE + el;
@@ -194,11 +198,11 @@ __global__ void __launch_bounds__(256) k_sortperm_rank_multi(const double* __res
     }
     if (m_elite < 2 || !active) return;
     // ---- elite early break (:458-461 / :566-569) by the last workgroup of the slot -------------------------------------------------------------
-    // (no fence: the skey entries are write-through agent-scope stores, drained before this workgroup's arrival is counted, and read back with
-    // agent-scope loads -- an agent-scope fence would write back the XCD's whole L2 once per workgroup)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Hand-off of the elite keys to the last workgroup of the slot: every workgroup's arrival is an ACQ_REL read-modify-write at agent scope --
+    // its release half orders this workgroup's skey stores before the count (across the XCDs' L2s, by the memory model rather than by the
+    // write-through behaviour of the stores), its acquire half makes the other workgroups' keys visible to the one that reads them.
     __syncthreads();
-    if (tid == 0) sh_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    if (tid == 0) sh_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
     __syncthreads();
     if (!sh_last) return;
     double mx = -INFINITY;

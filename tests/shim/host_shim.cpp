@@ -10,7 +10,7 @@ static Track mk(int P, const double* tx, const double* ty, const double* tw, std
     n2.resize(P); for (int i = 0; i < P; ++i) n2[i] = tx[i] * tx[i] + ty[i] * ty[i];
     const int W = std::min<int>(kTrackNbrW, P);
     build_track_tables(P, tx, ty, g_nd, g_ni);
-    build_track_ring(P, tx, ty, tw, g_nd, g_ring, g_cert);
+    build_track_ring(P, tx, ty, tw, n2.data(), g_nd, g_ring, g_cert);
     return Track{tx, ty, tw, n2.data(), P, g_ni.data(), g_nd.data(), W, g_ring.data(), g_cert.data()};
 }
 extern "C" {

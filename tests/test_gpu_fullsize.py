@@ -124,11 +124,13 @@ def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
     eng.close()
 
 
-@pytest.mark.parametrize("P,ncars", [(300, 1), (960, 1), (2048, 1), (960, 3)])
+@pytest.mark.parametrize("P,ncars", [(300, 1), (960, 1), (2048, 1), (960, 3), (203, 1), (221, 1), (222, 3), (231, 1)])
 def test_large_tracks_rollout_costs(eng_mod, oracle, P, ncars):
     """Track(infile; sample_factor = 1) has ~960 points (car_racing_tracks.jl:16-23; the default factor 20 gives 48): beyond ~230 points the
     track tables no longer fit the rollout kernels' default LDS budget -- only the ring table of the straight-line nearest-point search is
-    staged and the general search reads global memory.  Costs against the oracle on a dense oval, some samples far off the track."""
+    staged and the general search reads global memory.  Costs against the oracle on a dense oval, some samples far off the track.
+    P = 203 .. 231 straddle the switch between the two layouts: the two-wave kernels (B = 2 here) add ~4.7 KB of static LDS to the dynamic
+    request, which at P = 221 / 222 used to total 65.7-66 KB without the kernels' LDS limit being raised."""
     a = np.linspace(0, 2 * np.pi, P, endpoint=False)
     trk = (np.ascontiguousarray(120 * np.cos(a) - 120), np.ascontiguousarray(60 * np.sin(a)), np.full(P, 15.0))
     K, T, B = 512, 30, 2

@@ -6,7 +6,11 @@
 #     calculate_trajectory_costs (src/mppi_mpopi_policies.jl:186,303,347,434,532,644,709,782), pol(env) (:121,:221),
 #     env(action), reward(env), within_track (src/envs/car_racing.jl:238,201; car_racing_tracks.jl:68)
 #
-#     julia --project=<MPOPIS checkout> tools/gen_golden.jl
+#     julia --project=<MPOPIS checkout> tools/gen_golden.jl            # write the vectors
+#     julia --project=<MPOPIS checkout> tools/gen_golden.jl --check    # write them, then re-load every file and assert shapes / draw counts
+#
+# --check makes one run self-validating: whoever has Julia for five minutes gets either usable files or an assertion that says which
+# file and which field is off (wrong number of randn! blocks for the policy, E not cs x K, resampling draws missing, ...).
 #
 # The reference draws from a MersenneTwister that the engine does not reproduce; parity is defined on identical standard
 # normals / resampling draws.  They are captured by WRAPPING the policy's RNG (nothing is re-derived): every randn! block,
@@ -147,3 +151,56 @@ try
 catch err
     @warn "MountainCar vectors skipped" err
 end
+
+# ---- --check: re-load what was just written and assert it has the layout tests/test_julia_golden.py consumes ---------------------------------
+function check_outputs()
+    files = filter(f -> startswith(f, "julia_") && endswith(f, ".json"), readdir(outdir))
+    @assert !isempty(files) "no julia_*.json in $outdir"
+    npol = 0
+    for f in sort(files)
+        d = JSON.parsefile(joinpath(outdir, f))
+        if f == "julia_within_track.json"
+            @assert length(d["track_x"]) == length(d["track_y"]) == length(d["track_w"]) "$f: track arrays differ in length"
+            @assert all(q -> haskey(q, "pos") && haskey(q, "within") && haskey(q, "dist"), d["queries"]) "$f: query fields"
+            continue
+        elseif startswith(f, "julia_env_steps_") || f == "julia_mountaincar_steps.json"
+            @assert d isa Vector && !isempty(d) "$f: expected a list of steps"
+            @assert all(st -> haskey(st, "a") && haskey(st, "state") && haskey(st, "reward"), d) "$f: step fields"
+            continue
+        end
+        npol += 1
+        K, T, N, nc = d["K"], d["T"], d["N"], d["num_cars"]
+        as, cs = 2nc, 2nc * T
+        pol = d["policy"]
+        @assert length(d["cost"]) == K "$f: cost has $(length(d["cost"])) entries, K = $K"
+        @assert length(d["weights"]) == K "$f: weights"
+        @assert length(d["control"]) == as "$f: control has $(length(d["control"])) entries, as = $as"
+        @assert length(d["U0"]) == cs && length(d["U_after"]) == cs "$f: U0 / U_after must have cs = $cs entries"
+        @assert length(d["state"]) == 8nc "$f: state"
+        @assert abs(sum(d["weights"]) - 1) < 1e-9 "$f: weights do not sum to 1"
+        nb = length(d["normals"])
+        if pol == "mppi"
+            # rand(rng, P, K, T) with P = MvNormal(as x as): K*T draws of an as-vector (src/mppi_mpopi_policies.jl:193)
+            @assert sum(length, d["normals"]) == K * T * as "$f: :mppi consumed $(sum(length, d["normals"])) normals, expected K*T*as = $(K * T * as)"
+            @assert length(d["E"]) == K * T "$f: E must hold K*T as-vectors"
+        else
+            iters = pol == "gmppi" ? 1 : N
+            # one randn! block of cs*K per executed iteration; CE / CMA may stop early (:459-461, :567-569)
+            @assert 1 <= nb <= iters "$f: $nb randn! blocks for N = $iters"
+            @assert all(b -> length(b) == cs * K, d["normals"]) "$f: a randn! block is not cs*K = $(cs * K) long"
+            @assert length(d["E"]) == cs * K "$f: E must be cs x K"
+            (pol in ("gmppi", "imppi", "μaismppi", "μΣaismppi", "pmcmppi")) && @assert nb == iters "$f: $pol draws every iteration ($nb of $iters blocks)"
+        end
+        if pol == "pmcmppi"
+            # Categorical alias sampler: one integer + one uniform per resampled column, (N-1) resampling rounds of K (:804-805)
+            @assert length(d["ints_1based"]) == (N - 1) * K "$f: $(length(d["ints_1based"])) alias integers, expected (N-1)*K = $((N - 1) * K)"
+            @assert length(d["unis"]) == (N - 1) * K "$f: alias uniforms"
+            @assert all(i -> 1 <= i <= K, d["ints_1based"]) "$f: alias integer out of 1:K"
+        else
+            @assert isempty(d["ints_1based"]) && isempty(d["unis"]) "$f: $pol must not consume resampling draws"
+        end
+    end
+    @assert npol >= 16 "only $npol policy cases written"
+    println("check ok: ", length(files), " files, ", npol, " policy cases -- commit tests/golden/julia_*.json and run pytest tests/test_julia_golden.py")
+end
+("--check" in ARGS) && check_outputs()
