@@ -37,15 +37,18 @@
 // some lane took the general sub-step, [2] lanes in it, [3] reward evaluations, [4] evaluations through the general nearest-point search
 #if defined(MPOPIS_PATH_STATS) && defined(__HIPCC__)
 static __device__ unsigned long long g_path_stats[8];
+static __device__ unsigned char g_sick[1 << 22];      // per thread of the launch: bit 0 took the general sub-step, bit 1 failed the 3-point ring certificate (own lane), bit 2 would fail a 5-point one
 #endif
 #if defined(MPOPIS_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define MPOPIS_STAT(i, n) do { const unsigned long long ex_ = __builtin_amdgcn_read_exec(); \
         if ((int)(threadIdx.x & 63) == __ffsll((long long)ex_) - 1) atomicAdd(&g_path_stats[i], (unsigned long long)(n)); } while (0)
 #define MPOPIS_STAT_LANES() __popcll(__builtin_amdgcn_read_exec())
+#define MPOPIS_SICK(bit) do { const size_t t_ = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; if (t_ < sizeof(g_sick)) g_sick[t_] |= (bit); } while (0)
 #endif
 #ifndef MPOPIS_STAT
 #define MPOPIS_STAT(i, n) do { } while (0)
 #define MPOPIS_STAT_LANES() 0
+#define MPOPIS_SICK(bit) do { } while (0)
 #endif
 
 namespace mpopis {
@@ -88,16 +91,20 @@ struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[
     // optional neighbour tables for the anchored nearest-point search (nullptr => always full scan):
     // row i = the nbrw points closest to q_i in ascending distance (rank 0 = i itself), row stride nbrw + 1
     const int* nbr_idx; const double* nbr_dist; int nbrw;
-    // optional ring table for the straight-line fast path of the rollout kernels (nullptr => within_track only): entry e, -2 <= e <= P+1,
-    // at ring[4 (e + 2) .. 4 (e + 2) + 3] = {x, y, |q|^2, lane_width} of track point e mod P -- the ring neighbours of any point are then at
-    // fixed offsets (no wrap-around index arithmetic); ring_cert[i] = ring_r2[i] (see below)
+    // optional ring table for the straight-line fast paths of the rollout kernels (nullptr => within_track only): entry e, -kRingPad <= e <= P-1+kRingPad,
+    // at ring[4 (e + kRingPad) .. +3] = {x, y, |q|^2, lane_width} of track point e mod P -- the ring neighbours of any point are then at
+    // fixed offsets (no wrap-around index arithmetic); ring_cert[i] = ring_r2[i], ring_cert[P + i] = ring5_r2[i] (see below)
     const double* ring = nullptr; const double* ring_cert = nullptr;
 };
+constexpr int kRingPad = 3;          // a nearest point up to two ring steps from the anchor, plus its own ring neighbours
 constexpr int kTrackNbrW = 16;
 // Row i of nbr_dist has one spare slot (index nbrw): it holds ring_r2[i] = (1 - 1e-9) x the squared distance from q_i to the nearest
 // track point that is NOT one of its ring neighbours {i-1, i, i+1} (+inf when there is none).  If a position p satisfies
 // 4 |p - q_i|^2 < ring_r2[i], every non-ring point j is farther from p than q_i is (|p - q_j| >= |q_j - q_i| - |p - q_i| > |p - q_i|),
 // so the nearest point is one of the three ring candidates -- the common case for a car that moved <= 3 m since the last step.
+// ring5_r2[i] is the same bound over the points outside {i-2 .. i+2}: on the bundled tracks (25 m between points, lane half-width 15 m) the
+// three-point certificate gives out ~12 m from the anchor -- cars use the width of the road, so mid-lap 10-35 % of the rollouts lose it at
+// some step and take their whole wave through the general search -- while the five-point one holds to ~18 m, i.e. everywhere inside the lane.
 
 }  // namespace mpopis
 #include <algorithm>
@@ -122,17 +129,27 @@ inline void build_track_tables(int P, const double* x, const double* y, std::vec
         nd[(size_t)i * S + W] = r2 * (1.0 - 1e-9);
     }
 }
+// host: (1 - 1e-9) x the squared distance from q_i to the nearest track point more than `width` ring steps away (+inf when there is none)
+inline double ring_cert_radius2(int P, const double* x, const double* y, int i, int width) {
+    double r2 = INFINITY;
+    for (int j = 0; j < P; ++j) {
+        int d = j > i ? j - i : i - j;
+        if (d > P - d) d = P - d;
+        if (d > width) r2 = fmin(r2, (x[j] - x[i]) * (x[j] - x[i]) + (y[j] - y[i]) * (y[j] - y[i]));
+    }
+    return r2 * (1.0 - 1e-9);
+}
 // n2[i] = |q_i|^2 exactly as the caller uploads it for the general search (one computation, copied: ring_candidates and within_track must
 // see bit-identical distances, or a near-tie could resolve differently depending on the path a wave took)
 inline void build_track_ring(int P, const double* x, const double* y, const double* w, const double* n2, const std::vector<double>& nd, std::vector<double>& ring, std::vector<double>& cert) {
     const int W = std::min<int>(kTrackNbrW, P), S = W + 1;
-    ring.assign((size_t)(P + 4) * 4, 0.0); cert.assign((size_t)P, 0.0);
-    for (int e = -2; e <= P + 1; ++e) {
+    ring.assign((size_t)(P + 2 * kRingPad) * 4, 0.0); cert.assign((size_t)2 * P, 0.0);
+    for (int e = -kRingPad; e < P + kRingPad; ++e) {
         const int i = ((e % P) + P) % P;
-        double* o = ring.data() + (size_t)(e + 2) * 4;
+        double* o = ring.data() + (size_t)(e + kRingPad) * 4;
         o[0] = x[i]; o[1] = y[i]; o[2] = n2[i]; o[3] = w[i];
     }
-    for (int i = 0; i < P; ++i) cert[i] = nd[(size_t)i * S + W];
+    for (int i = 0; i < P; ++i) { cert[i] = nd[(size_t)i * S + W]; cert[P + i] = ring_cert_radius2(P, x, y, i, 2); }
 }
 
 // Rounding discipline of everything below: NO implicit a*b + c.  hipcc's default (-ffp-contract=fast, which this library is built with) lets the
@@ -254,7 +271,7 @@ MP_HD TireK tire_consts(double mufz, double Ca, double fxt) {                  /
 // Car state as the kernels carry it: the reference's 8 doubles plus sin/cos of psi and delta, which
 // are advanced by angle addition and never re-evaluated inside a rollout.
 struct CarState { double x, y, psi, Vx, Vy, r, delta, pedal, sp, cp, sd, cd; int near; };   // near: nearest track point of the last reward (-1: unknown)
-constexpr int kCarExt = 12;
+constexpr int kCarExt = 13;      // 8 state doubles, sin / cos of psi and delta, and the track point nearest to the start position (as a double)
 
 MP_HD void car_state_from8(CarState& c, const double* s) {     // the only place sin/cos are evaluated
     c.x = s[0]; c.y = s[1]; c.psi = s[2]; c.Vx = s[3]; c.Vy = s[4]; c.r = s[5]; c.delta = s[6]; c.pedal = s[7];
@@ -302,7 +319,10 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
     const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);                  // :262-272 (same derived constants as the hot path)
     const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
-    const double fx_aero = fma(p.CD1, fabs(Vx), p.CD0) * sg;                              // :308
+    // :308 (CD1 |Vx| + CD0) sign(Vx).  The sign is applied by selection, not by a multiply: `fxr - t * sg` would be a product feeding a subtract,
+    // which -ffp-contract=fast fuses (harmlessly here, t * (+-1) is exact -- but the model code keeps no such pattern, see "Rounding discipline")
+    const double f_drag = fma(p.CD1, fabs(Vx), p.CD0);
+    const double fx_aero = (Vx > 0.0) ? f_drag : ((Vx < 0.0) ? -f_drag : f_drag * sg);
     const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
     double fyr;
     if (Vx > 0.0 && fabs(yr / Vx) < kr.thr) fyr = tire_poly(yr / Vx, p.Car, kr);
@@ -315,7 +335,7 @@ MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, doub
     // :322-328 with the same δt-folded constants as the hot path (k_rf = δt l_f/Izz, k_rr = δt l_r/Izz, k_v = δt/m)
     const double flat = fma(fyf, cd, fxf * sd), flon = fma(fxf, cd, -(fyf * sd)), rd = r * p.ddt;
     const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));
-    const double Vx1 = fma(p.k_v, flon + fma(1 - lam, fx, -fx_aero), fma(rd, Vy, Vx));      // (fxr - fx_aero with fxr = (1-λ) fx: written as the fma it is)
+    const double Vx1 = fma(p.k_v, flon + (fxr - fx_aero), fma(rd, Vy, Vx));
     r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));
     Vx = Vx1; Vy = Vy1;
     double dpsi = r * p.ddt;
@@ -394,7 +414,7 @@ MP_HD void car_integrate(const CarParams& p, const ActionConsts& k, SteerF&& ste
         const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
         const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
         if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
-            MPOPIS_STAT(1, 1); MPOPIS_STAT(2, MPOPIS_STAT_LANES());
+            MPOPIS_STAT(1, 1); MPOPIS_STAT(2, MPOPIS_STAT_LANES()); MPOPIS_SICK(1);
             car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
             rdt = r * p.ddt;
             return;
@@ -557,7 +577,7 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
 // track_project, so the result never depends on the path taken.  rel (out) = nearest point - anchor in ring steps (-1, 0, +1).
 MP_HD bool ring_candidates(const double* ring, const double* cert, int a0, double px, double py, int* rel) {
     const int a = a0 < 0 ? 0 : a0;                                             // branch-free: a missing anchor reads entry 0 and reports "not applicable"
-    const double* e0 = ring + (size_t)4 * (a + 2);
+    const double* e0 = ring + (size_t)4 * (a + kRingPad);
     const double m2x = -2.0 * px, m2y = -2.0 * py;
     const double d0 = fma(e0[1], m2y, fma(e0[0], m2x, e0[2]));                 // |q|^2 - 2 q.p, as in within_track
     const double dm = fma(e0[-3], m2y, fma(e0[-4], m2x, e0[-2]));
@@ -567,10 +587,33 @@ MP_HD bool ring_candidates(const double* ring, const double* cert, int a0, doubl
     *rel = (dm < d0 && dm < dp) ? -1 : ((dp < d0 && dp < dm) ? 1 : 0);
     return ok;
 }
+// Second tier, tried by a wave in which some lane failed the three-point test: five candidates {a0-2 .. a0+2} under the wider certificate
+// cert5 = ring_cert + P (see Track).  Applies when that certificate holds and the smallest of the five distances is attained ONCE (a tie would
+// have to be broken by track index, which the general search does).  rel (out) in -2 .. 2.
+MP_HD bool ring5_candidates(const double* ring, const double* cert5, int a0, double px, double py, int* rel) {
+    const int a = a0 < 0 ? 0 : a0;
+    const double* e0 = ring + (size_t)4 * (a + kRingPad);
+    const double m2x = -2.0 * px, m2y = -2.0 * py;
+    const double d0 = fma(e0[1], m2y, fma(e0[0], m2x, e0[2]));
+    const double dm = fma(e0[-3], m2y, fma(e0[-4], m2x, e0[-2]));
+    const double dp = fma(e0[5], m2y, fma(e0[4], m2x, e0[6]));
+    const double dmm = fma(e0[-7], m2y, fma(e0[-8], m2x, e0[-6]));
+    const double dpp = fma(e0[9], m2y, fma(e0[8], m2x, e0[10]));
+    const double D02 = d0 + fma(px, px, py * py);
+    double best = d0; int r = 0;
+    if (dm < best) { best = dm; r = -1; }
+    if (dp < best) { best = dp; r = 1; }
+    if (dmm < best) { best = dmm; r = -2; }
+    if (dpp < best) { best = dpp; r = 2; }
+    const int hits = (d0 == best) + (dm == best) + (dp == best) + (dmm == best) + (dpp == best);
+    *rel = r;
+    return (a0 >= 0) & (4.0 * D02 < cert5[a]) & (hits == 1);                   // (a NaN position fails the certificate)
+}
 MP_HD bool ring_project(const double* ring, int a0, int rel, double px, double py, double* dist_out) {
-    const double* e = ring + (size_t)4 * (a0 + rel + 2);
+    const double* e = ring + (size_t)4 * (a0 + rel + kRingPad);
     return track_project(px, py, e[0], e[1], e[-4], e[-3], e[4], e[5], e[3], dist_out);
 }
+MP_HD int ring_wrap(int mi, int P) { return (mi < 0) ? mi + P : ((mi >= P) ? mi - P : mi); }
 
 // reward(env::CarRacingEnv): src/envs/car_racing.jl:201-213
 // |atan2(Vy,Vx)| > β_limit without the atan2 (tan_blim = tan(β_limit) or tan(pi-β_limit), host-side)
@@ -596,10 +639,24 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
     // wave through the general search (first step of a rollout, a lane far off its anchor, exact ties)
     const bool fast = tk.ring && anchor && ring_candidates(tk.ring, tk.ring_cert, *anchor, x, y, &rel);
     MPOPIS_STAT(3, 1);
+#if defined(MPOPIS_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    if (tk.ring && anchor && *anchor >= 0 && !fast) {
+        MPOPIS_SICK(2);
+        // would a 5-point ring certificate hold?  radius = half the distance from the anchor to the nearest point outside {a-2..a+2} (brute force here)
+        const int a_ = *anchor; double r2_ = INFINITY;
+        for (int j_ = 0; j_ < tk.P; ++j_) { int d_ = j_ - a_; if (d_ < 0) d_ = -d_; if (d_ > tk.P - d_) d_ = tk.P - d_; if (d_ > 2) { const double ex_ = tk.ring[4 * (j_ + kRingPad)] - tk.ring[4 * (a_ + kRingPad)], ey_ = tk.ring[4 * (j_ + kRingPad) + 1] - tk.ring[4 * (a_ + kRingPad) + 1]; r2_ = fmin(r2_, ex_ * ex_ + ey_ * ey_); } }
+        const double dx_ = x - tk.ring[4 * (a_ + kRingPad)], dy_ = y - tk.ring[4 * (a_ + kRingPad) + 1];
+        if (!(4.0 * (dx_ * dx_ + dy_ * dy_) < r2_)) MPOPIS_SICK(4);
+    }
+#endif
     if (__builtin_expect(tk.ring && anchor && wave_all(fast), 1)) {
         within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
-        const int mi = *anchor + rel;
-        *anchor = (mi < 0) ? tk.P - 1 : ((mi >= tk.P) ? 0 : mi);
+        *anchor = ring_wrap(*anchor + rel, tk.P);
+    } else if (tk.ring && anchor && tk.P >= 5 && wave_all(ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, x, y, &rel))) {
+        // some lane is farther from its anchor than the three-point certificate reaches (a car using the width of the road): five candidates, same tail
+        MPOPIS_STAT(5, 1);
+        within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
+        *anchor = ring_wrap(*anchor + rel, tk.P);
     } else {
         MPOPIS_STAT(4, 1);
         within = within_track(tk, x, y, &dist, anchor);

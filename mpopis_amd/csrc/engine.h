@@ -69,7 +69,7 @@ struct RolloutArgs {
     EnvDesc env;
     int B, K, T, cs;
     const double* x0;      // [B][ss]   (MountainCar)
-    const double* x0ext;   // [B][ncars][12] car start states + sin/cos (launch_extend_state)
+    const double* x0ext;   // [B][ncars][kCarExt] car start states + sin/cos + nearest track point (launch_extend_state)
     const int* t0;         // [B] (MountainCar step counter) or nullptr
     const int* done0;      // [B]
     const double* Ucur;    // [B][cs]
@@ -112,9 +112,9 @@ __device__ __forceinline__ void status_raise(int* p, int code) {
 }
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
-void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s);
+void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s, const Track& tk);
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin = nullptr);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk);
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,

@@ -717,7 +717,7 @@ int mpopis_bench_policy_steps(mpopis_handle* h, int32_t steps, double* ms, doubl
 
 // ---- launch sequences -----------------------------------------------------------------------------
 void mpopis_handle::prepare_state() {
-    if (env.kind == MPOPIS_ENV_CAR) launch_extend_state(d_x, d_xext, B, env.ncars, stream);
+    if (env.kind == MPOPIS_ENV_CAR) launch_extend_state(d_x, d_xext, B, env.ncars, stream, env.track);
 }
 
 void mpopis_handle::rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters, int iter_n) {
@@ -805,7 +805,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
     // status / active / iters reset, U_orig = pol.U (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop), extended start states
     launch_step_begin(status_sticky ? nullptr : d_status, d_active, alive_gate, d_iters, d_U, d_Uin, d_Ucur, B, cs,
-                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream, weights_in_moments ? d_cmin : nullptr);
+                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream, weights_in_moments ? d_cmin : nullptr, env.track);
     if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
     if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
     // Shapes the fused sampler does not cover (cs > 128: Z goes through memory anyway) with device RNG, a dense proposal from iteration 2 on

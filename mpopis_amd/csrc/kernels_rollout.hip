@@ -21,17 +21,17 @@ namespace mpopis {
 
 // One car (NC = 1, CarRacingEnv): SPB sample-waves per workgroup share one LDS copy of the track tables
 // LOG: the trajectory logger is on (a.traj != nullptr) -- only then is the heading angle psi itself tracked
-// Track tables into LDS (dynamic LDS layout: ring table [(P+4)][4] + certification radii [P]; with ALL: + x, y, w, |q|^2 [4][P] + neighbour
+// Track tables into LDS (dynamic LDS layout: ring table [(P+6)][4] + certification radii [2][P]; with ALL: + x, y, w, |q|^2 [4][P] + neighbour
 // distances [P][W+1] + neighbour indices [P][W+1]).  Returns the Track the rollout uses; the caller synchronises.
 template <bool ALL>
 __device__ __forceinline__ Track stage_track(const Track& g, double* sh, int tid, int nthreads) {
     const int P = g.P, W = g.nbrw, NS = P * (W + 1);
     double* sh_ring = sh;
-    double* sh_cert = sh + 4 * (P + 4);
-    for (int i = tid; i < 4 * (P + 4); i += nthreads) sh_ring[i] = g.ring[i];
-    for (int i = tid; i < P; i += nthreads) sh_cert[i] = g.ring_cert[i];
+    double* sh_cert = sh + 4 * (P + 2 * kRingPad);
+    for (int i = tid; i < 4 * (P + 2 * kRingPad); i += nthreads) sh_ring[i] = g.ring[i];
+    for (int i = tid; i < 2 * P; i += nthreads) sh_cert[i] = g.ring_cert[i];      // three-point and five-point certificates
     if (!ALL) return Track{g.x, g.y, g.w, g.n2, P, g.nbr_idx, g.nbr_dist, W, sh_ring, sh_cert};
-    double* sh_trk = sh_cert + P;
+    double* sh_trk = sh_cert + 2 * P;
     double* sh_nd = sh_trk + 4 * P;
     int* sh_ni = reinterpret_cast<int*>(sh_nd + NS);
     for (int i = tid; i < P; i += nthreads) { sh_trk[i] = g.x[i]; sh_trk[P + i] = g.y[i]; sh_trk[2 * P + i] = g.w[i]; sh_trk[3 * P + i] = g.n2[i]; }
@@ -39,7 +39,7 @@ __device__ __forceinline__ Track stage_track(const Track& g, double* sh, int tid
     return Track{sh_trk, sh_trk + P, sh_trk + 2 * P, sh_trk + 3 * P, P, sh_ni, sh_nd, W, sh_ring, sh_cert};
 }
 inline size_t track_lds_bytes(int P, int W, bool all) {
-    return (size_t)(4 * (P + 4) + P) * sizeof(double) + (all ? (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int)) : 0);
+    return (size_t)(4 * (P + 2 * kRingPad) + 2 * P) * sizeof(double) + (all ? (size_t)4 * P * sizeof(double) + (size_t)P * (W + 1) * (sizeof(double) + sizeof(int)) : 0);
 }
 
 // TLDS: every track table fits the default 64 KB of dynamic LDS (P <= ~230 points: all bundled tracks).  Otherwise only the ring table of the
@@ -59,6 +59,11 @@ extern "C" int mpopis_debug_roll_prof(unsigned long long* out) { return (int)hip
 extern "C" int mpopis_debug_path_stats(unsigned long long* out, int reset) {      // dev build: read (and optionally clear) the path counters of car_dynamics.h
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_path_stats), sizeof(g_path_stats));
     if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z); }
+    return rc;
+}
+extern "C" int mpopis_debug_sick(unsigned char* out, int n, int reset) {       // per-thread flags of the launches since the last reset
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sick), (size_t)n);
+    if (reset) { void* p = nullptr; rc |= (int)hipGetSymbolAddress(&p, HIP_SYMBOL(g_sick)); rc |= (int)hipMemset(p, 0, sizeof(g_sick)); }
     return rc;
 }
 #endif
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
         s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
-        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = (int)xe[12];
     }
     const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
     const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
         {
             const double* xe = a.x0ext + (size_t)b * kCarExt;
             s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
-            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = (int)xe[12];
         }
         const double* Eb = a.E + (size_t)b * a.cs * K + kk;
         const double* Ub = a.Ucur + (size_t)b * a.cs;
@@ -204,7 +209,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))
         return;
     }
     double cost = 0.0;
-    int near = -1;
+    int near = (int)a.x0ext[(size_t)b * kCarExt + 12];                         // the anchor of the first search: the track point nearest to the start position
     for (int t = 0; t < T; ++t) {
         while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
         const int slot = t & 1;
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(64 * SPB) __attribute__((amdgpu_waves_per_eu(W
     {
         const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
         s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
-        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+        s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = (int)xe[12];
     }
     const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
     const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
@@ -349,7 +354,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         {
             const double* xe = a.x0ext + ((size_t)b * NC + c) * kCarExt;
             s.x = xe[0]; s.y = xe[1]; s.psi = xe[2]; s.Vx = xe[3]; s.Vy = xe[4]; s.r = xe[5]; s.delta = xe[6]; s.pedal = xe[7];
-            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = -1;
+            s.sp = xe[8]; s.cp = xe[9]; s.sd = xe[10]; s.cd = xe[11]; s.near = (int)xe[12];
         }
         const double* Eb = a.E + (size_t)b * a.cs * K + (size_t)(2 * c) * K + kk;
         const double* Ub = a.Ucur + (size_t)b * a.cs + 2 * c;
@@ -376,7 +381,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
         return;
     }
     double cost = 0.0;
-    int near = -1;
+    int near = (int)a.x0ext[((size_t)b * NC + c) * kCarExt + 12];
     for (int t = 0; t < T; ++t) {
         while (__hip_atomic_load(&sh_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
         const int slot = t & 1;
@@ -447,40 +452,43 @@ __global__ void __launch_bounds__(64) k_rollout_simple(RolloutArgs a) {
 
 // x0ext[b][car][12] = env state + sin/cos(psi), sin/cos(delta): evaluated once per trial and car
 // instead of once per sample (the start state is shared by all K rollouts).
-__global__ void k_extend_state(const double* x, double* xext, int n_cars_total) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_cars_total) return;
+// ... and the track point nearest to the start position (full scan, once per trial and car): the anchor of every rollout's first nearest-point
+// search, which then takes the ring paths like every later step instead of sending the whole wave through the general search
+__device__ __forceinline__ void write_xext(const double* x8, double* o, const Track& tk) {
     CarState c;
-    car_state_from8(c, x + (size_t)i * 8);
-    double* o = xext + (size_t)i * kCarExt;
+    car_state_from8(c, x8);
     o[0] = c.x; o[1] = c.y; o[2] = c.psi; o[3] = c.Vx; o[4] = c.Vy; o[5] = c.r; o[6] = c.delta; o[7] = c.pedal;
     o[8] = c.sp; o[9] = c.cp; o[10] = c.sd; o[11] = c.cd;
+    int near = -1;
+    if (tk.P > 0) { double dist; (void)within_track(tk, c.x, c.y, &dist, &near); }
+    o[12] = (double)near;
 }
-void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t st) {
+__global__ void k_extend_state(const double* x, double* xext, int n_cars_total, Track tk) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_cars_total) return;
+    write_xext(x + (size_t)i * 8, xext + (size_t)i * kCarExt, tk);
+}
+void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t st, const Track& tk) {
     const int n = B * ncars;
-    hipLaunchKernelGGL(k_extend_state, dim3((n + 63) / 64), dim3(64), 0, st, x, xext, n);
+    hipLaunchKernelGGL(k_extend_state, dim3((n + 63) / 64), dim3(64), 0, st, x, xext, n, tk);
 }
 
 // Start of an MPC step, one launch instead of seven (at one trial the step is a chain of dependent launches, each boundary costs 2-4 us):
 // status = 0 (unless sticky), active = alive gate (or 1), iters = 0, U_orig = the loop's pol.U = pol.U, and the car start states extended
 // with sin/cos of psi / delta (as k_extend_state).
 __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur,
-                                                    int cs, const double* x, double* xext, int ncars, unsigned long long* cmin) {
+                                                    int cs, const double* x, double* xext, int ncars, unsigned long long* cmin, Track tk) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; if (cmin) cmin[b] = ~0ull; }
     for (int i = tid; i < cs; i += 256) { const double u = U[(size_t)b * cs + i]; Uin[(size_t)b * cs + i] = u; Ucur[(size_t)b * cs + i] = u; }
     if (x && tid < ncars) {
         const size_t i = (size_t)b * ncars + tid;
-        CarState c;
-        car_state_from8(c, x + i * 8);
-        double* o = xext + i * kCarExt;
-        o[0] = c.x; o[1] = c.y; o[2] = c.psi; o[3] = c.Vx; o[4] = c.Vy; o[5] = c.r; o[6] = c.delta; o[7] = c.pedal;
-        o[8] = c.sp; o[9] = c.cp; o[10] = c.sd; o[11] = c.cd;
+        write_xext(x + i * 8, xext + i * kCarExt, tk);
     }
 }
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin) {
-    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk) {
+    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin, tk);
 }
 
 // Dynamic LDS a rollout kernel may request without raising its limit: the default 64 KB minus the kernels' STATIC LDS (two-wave kernels:

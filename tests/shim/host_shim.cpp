@@ -49,12 +49,15 @@ extern "C" int shim_within_ring(int P, const double* tx, const double* ty, const
     static std::vector<double> n2; static Track tk; static const double* last = nullptr;
     if (last != tx) { tk = mk(P, tx, ty, tw, n2); last = tx; }
     int rel = 0;
-    const bool ok = ring_candidates(tk.ring, tk.ring_cert, *anchor, px, py, &rel);
+    bool ok = ring_candidates(tk.ring, tk.ring_cert, *anchor, px, py, &rel);
     *fast = ok ? 1 : 0;
+    if (!ok && tk.P >= 5) {                                    // second tier of car_reward: five candidates under the wider certificate
+        ok = ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, px, py, &rel);
+        if (ok) *fast = 2;
+    }
     if (ok) {
         const bool w = ring_project(tk.ring, *anchor, rel, px, py, dist);
-        const int mi = *anchor + rel;
-        *anchor = (mi < 0) ? tk.P - 1 : ((mi >= tk.P) ? 0 : mi);
+        *anchor = ring_wrap(*anchor + rel, tk.P);
         return w ? 1 : 0;
     }
     return within_track(tk, px, py, dist, anchor) ? 1 : 0;

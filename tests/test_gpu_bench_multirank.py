@@ -79,5 +79,6 @@ def test_bench_single_gpu_line_has_every_baseline_config():
         assert c["ms_per_step"] > 0 and c["rollouts_per_s"] > 0 and c["dominant"]["avg_launch_us"] > 0
         assert abs(sum(c["kernel_ms_per_step"].values()) - c["ms_per_step"]) < 0.5 * c["ms_per_step"]      # kernel classes account for the step
         # the reference's call pattern: one synchronous pol(env) per MPC step through the C ABI, one wait instead of four
-        assert 0 < c["abi_sync_ms_per_step"] < 3 * c["ms_per_step"] + 0.2 and c["abi_sync"]["steps"] >= 5
-        assert c["abi_sync_ms_per_step"] <= 1.05 * c["abi_four_call_ms_per_step"]
+        assert 0 < c["abi_sync_ms_per_step"] < 3 * c["ms_per_step"] + 0.2 and c["abi_sync"]["closed_loop"]["steps"] >= 5
+        assert c["abi_sync"]["closed_loop"]["median"] <= 1.05 * c["abi_four_call_ms_per_step"]      # same loop, one wait instead of four
+        assert c["resident_closed_loop_ms_per_step"] > 0

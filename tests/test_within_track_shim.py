@@ -63,7 +63,7 @@ def test_anchored_search_matches_findmin(shim, oracle, name, track):
 
 @pytest.mark.parametrize("name,track", _tracks(), ids=[n for n, _ in _tracks()])
 def test_ring_fast_path_matches_findmin_and_general_search(shim, oracle, name, track):
-    """The rollout kernels' straight-line path (ring table, certified candidates, no ties) against the oracle's literal findmin AND bit for bit
+    """The rollout kernels' straight-line paths (ring table; three certified candidates, else five under the wider certificate; no ties) against the oracle's literal findmin AND bit for bit
     against the general anchored search from the same anchor: a rollout's cost must not depend on which of the two a wave took."""
     tx, ty, tw = (np.ascontiguousarray(a, dtype=np.float64) for a in track)
     L = shim
@@ -73,7 +73,7 @@ def test_ring_fast_path_matches_findmin_and_general_search(shim, oracle, name, t
     anchor = C.c_int(-1)
     k = int(rng.integers(0, P))
     pos = np.array([tx[k], ty[k]]) + rng.normal(0, 3, 2)
-    nfast = 0
+    nfast = nfast5 = 0
     nq = 1500
     for q in range(nq):
         if q % 97 == 0:
@@ -87,10 +87,12 @@ def test_ring_fast_path_matches_findmin_and_general_search(shim, oracle, name, t
         args = (P, tx.ctypes.data_as(dp), ty.ctypes.data_as(dp), tw.ctypes.data_as(dp), float(pos[0]), float(pos[1]))
         w_gen = L.shim_within_anchor(*args, C.byref(a_gen), C.byref(d_gen))
         w_ring = L.shim_within_ring(*args, C.byref(a_ring), C.byref(d_ring), C.byref(fast))
-        nfast += fast.value
+        nfast += fast.value == 1
+        nfast5 += fast.value == 2                                # the five-candidate tier (a lane beyond the three-point certificate)
         assert w_ring == w_gen and a_ring.value == a_gen.value and d_ring.value == d_gen.value, (name, q, pos, fast.value)   # bit-identical
         rw, rd = oracle.within_track((tx, ty, tw), pos)
         assert bool(w_ring) == rw and abs(d_ring.value - rd) <= 1e-9 * max(1.0, rd)
         anchor = a_ring
     if P >= 8 and name != "hairpin":
         assert nfast > nq // 3, (name, nfast)                    # the fast path is common even on this random walk with excursions
+        assert nfast5 > nq // 50, (name, nfast5)                 # ... and the second tier picks up a good part of what the first one misses

@@ -17,19 +17,30 @@ L = _lib.lib()
 buf = (C.c_ulonglong * 8)()
 
 
-def point(tag):
+nth = B * (K if cars == 1 else ((K + (64 // cars) - 1) // (64 // cars)) * 64)
+sick = (C.c_ubyte * nth)()
+
+
+def point(tag, n):
+    """n closed-loop MPC steps (mpopis_run_trials: the state moves, pol.U follows it), counters over that window; then ONE more step for the
+    per-thread flags (OR over that step's N rollouts of a thread's sample index: per-rollout share = 1 - (1 - f)^(1/N) if independent)"""
+    import time
     L.mpopis_debug_path_stats(buf, 1)
-    ms, _ = eng.bench_policy_steps(5)
+    t0 = time.perf_counter(); eng.run_trials(num_steps=n - 1, laps=4); ms = (time.perf_counter() - t0) * 1e3
     L.mpopis_debug_path_stats(buf, 1)
     s = [int(v) for v in buf]
-    print("%-28s %.3f ms/step | sub-steps %d, with a general lane %.4f (lanes per such wave %.1f) | rewards %d, general search %.4f" % (
-        tag, ms / 5, s[0], s[1] / max(1, s[0]), s[2] / max(1, s[1]), s[3], s[4] / max(1, s[3])), flush=True)
+    L.mpopis_debug_sick(sick, nth, 1)
+    eng.run_trials(num_steps=0, laps=4)
+    L.mpopis_debug_sick(sick, nth, 1)
+    f = np.frombuffer(sick, dtype=np.uint8)
+    inv = lambda v: 1 - (1 - v) ** (1.0 / N)
+    x = eng.get_state()[0]
+    print("%-26s %.3f ms/step | sub-steps with a general lane %.4f | rewards through the general search %.4f (five-point tier %.4f) | per rollout (est.): general sub-step %.4f, 3-ring fails %.4f, 5-ring fails %.4f | slot0 Vx=%.1f" % (
+        tag, ms / n, s[1] / max(1, s[0]), s[4] / max(1, s[3]), s[5] / max(1, s[3]), inv((f & 1).astype(bool).mean()), inv((f & 2).astype(bool).mean()), inv((f & 4).astype(bool).mean()), x[0, 3]), flush=True)
 
 
-point("reset state")
 done = 0
-for n in (40, 60, 100):
-    eng.run_trials(num_steps=n - 1, laps=4)
-    done += n
-    point("after %d closed-loop steps" % done)
+for n in (10, 30, 30, 30, 50, 50):
+    point("closed-loop steps %d..%d" % (done, done + n), n)
+    done += n + 1
 eng.close()
