@@ -40,7 +40,7 @@ def point(tag, n):
 
 
 done = 0
-for n in (10, 30, 30, 30, 50, 50):
+for n in ((4, 4) if pol == "cmamppi" else (10, 30, 30, 30, 50, 50)):
     point("closed-loop steps %d..%d" % (done, done + n), n)
     done += n + 1
 eng.close()
