@@ -127,6 +127,15 @@ __global__ void __launch_bounds__(64 * NC * SPB) __attribute__((amdgpu_waves_per
     }
     cost += cc;
     const double total = cost;
+#ifdef MPOPIS_PATH_STATS
+    {   // dev build: rollouts of this launch that took the general sub-step at least once / that end stopped (per launch: flags cleared)
+        const size_t t_ = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool went = t_ < sizeof(g_sick) && (g_sick[t_] & 1);
+        if (t_ < sizeof(g_sick)) g_sick[t_] = 0;
+        const int nw = __popcll(__ballot(went)), ns = __popcll(__ballot(!(s.Vx > 0.5)));
+        if (lane == 0) { atomicAdd(&g_path_stats[6], (unsigned long long)nw); atomicAdd(&g_path_stats[7], (unsigned long long)ns); }
+    }
+#endif
     if (valid) a.cost[(size_t)b * K + k] = total;
     if (a.cmin) {
         // ρ = minimum(costs) (utils.jl:81) accumulates here, one atomic per wave, so that the AIS reweighting can be folded into the moments

@@ -35,10 +35,21 @@ def point(tag, n):
     f = np.frombuffer(sick, dtype=np.uint8)
     inv = lambda v: 1 - (1 - v) ** (1.0 / N)
     x = eng.get_state()[0]
+    print("    rollouts that took the general sub-step %.4f, that end with Vx <= 0.5: %.4f" % (s[6] / max(1, s[0] // 500 * 64), s[7] / max(1, s[0] // 500 * 64)))
     print("%-26s %.3f ms/step | sub-steps with a general lane %.4f | rewards through the general search %.4f (five-point tier %.4f) | per rollout (est.): general sub-step %.4f, 3-ring fails %.4f, 5-ring fails %.4f | slot0 Vx=%.1f" % (
         tag, ms / n, s[1] / max(1, s[0]), s[4] / max(1, s[3]), s[5] / max(1, s[3]), inv((f & 1).astype(bool).mean()), inv((f & 2).astype(bool).mean()), inv((f & 4).astype(bool).mean()), x[0, 3]), flush=True)
 
 
+if os.environ.get("FROZEN"):                                 # frozen-state policy steps after n closed-loop steps (what tools/midlap_bench.py times)
+    eng.run_trials(num_steps=99, laps=4)
+    for rep in range(2):
+        L.mpopis_debug_path_stats(buf, 1)
+        ms, _ = eng.bench_policy_steps(5)
+        L.mpopis_debug_path_stats(buf, 1)
+        s = [int(v) for v in buf]
+        nro = s[0] // 500 * 64
+        print("frozen at step 100: %.2f ms/step | sub-steps with a general lane %.4f | general search %.4f (tier 5: %.4f) | rollouts that took the general sub-step %.4f, that end with Vx <= 0.5: %.4f" % (ms / 5, s[1] / max(1, s[0]), s[4] / max(1, s[3]), s[5] / max(1, s[3]), s[6] / max(1, nro), s[7] / max(1, nro)))
+    eng.close(); sys.exit(0)
 done = 0
 for n in ((4, 4) if pol == "cmamppi" else (10, 30, 30, 30, 50, 50)):
     point("closed-loop steps %d..%d" % (done, done + n), n)

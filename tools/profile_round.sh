@@ -9,14 +9,14 @@ O=$R/gpurun_out/$TAG
 mkdir -p "$O"
 cd "$R" && python bench.py --multi-stream > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-configs --repeats 0 > "$O/prof_bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-midlap --repeats 0 > "$O/prof_bench.log" 2>&1
 head -8 "$O"/prof/bench_kernel_stats.csv | cut -c1-160
 for P in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
          "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM"; do
     N=$(echo $P | cut -d" " -f1)
-    rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$O/pmc/$N" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --repeats 0 > "$O/pmc_$N.log" 2>&1
+    rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$O/pmc/$N" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-midlap --repeats 0 > "$O/pmc_$N.log" 2>&1
 done
 ls "$O"/pmc/*/ | head -20
 # summaries on the box (gpurun merges at most 64 MiB back): per-kernel PMC table + pmc_rollout.json next to the raw passes, then drop the per-dispatch dumps
