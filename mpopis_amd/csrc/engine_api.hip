@@ -222,7 +222,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_dscale, (size_t)B * cs); rc |= dalloc(h, &h->d_dscale0, (size_t)cs);
     rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B); rc |= dalloc(h, &h->d_wsum, B); rc |= dalloc(h, &h->d_cmin, B);
     rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
-    rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, 2 * (128 + 64));
+    rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, 2 * (256 + 128));      // philox.h: kRngTabDoubles
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);

@@ -33,10 +33,14 @@ constexpr int kTrmmLd = kTrmmRows + 16;             // LDS row stride = 16 (mod 
 struct RngArgs { const uint64_t* seeds; uint32_t slo, shi; const double* tab; const double* panel; size_t pstride; const double* oscale2; };
 // 4 waves per SIMD (128 VGPRs; the LDS panel allows 4 workgroups per CU): measured 5 % faster than the default 3 for the fused
 // sampler (Philox / Box-Muller VALU work of one wave fills the slots in which another waits on the matrix cores)
-template <bool RNG>
+// LD: LDS row stride of the panel in doubles, = 16 (mod 32) for conflict-free operand reads.  kTrmmLd = 144 holds all 8 row tiles; 112 (7 row
+// tiles, no padding needed: 112 = 16 mod 32) is what every 1-car H = 50 shape needs and leaves room for the Box-Muller tables (6 KB) at four
+// workgroups per CU: 2 x 16 x 112 x 8 + 6 KB = 34.7 KB (with the 144-stride panel the round-3 tables of 3 KB were all that fitted: 159.7 of 160 KB)
+template <bool RNG, int LD = kTrmmLd>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_trmm_LZ_mfma(const double* __restrict__ L, size_t Lstride, const double* __restrict__ Z,
                                                       double* __restrict__ E, int n, int K, const int* active, RngArgs rng, int tpg) {
-    __shared__ double Ls[2][16][kTrmmLd];
+    __shared__ double Ls[2][16][LD];
+    constexpr int TT = LD >= kTrmmRows ? kTrmmTiles : LD / 16;       // row tiles this instantiation can hold
     __shared__ double sh_tab[RNG ? kRngTabDoubles : 1];
     const int b = blockIdx.z;
     if (active && !active[b]) return;
@@ -52,9 +56,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int li = lane & 15, lk = lane >> 4;
     const int kcol = min(k0 + li, K - 1);
     const bool wave_on = k0 < K;
-    v4f64 acc[kTrmmTiles];
+    v4f64 acc[TT];
 #pragma unroll
-    for (int t = 0; t < kTrmmTiles; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int jend = min(n, (t0 + nt) * 16);                   // lower triangular: j <= i
     // staging map: thread -> row si of the pass, columns sj + 2u (u < 8) of the chunk
     const int si = threadIdx.x & (kTrmmRows - 1), sj = threadIdx.x >> 7;
@@ -96,8 +100,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     int buf = 0;
     for (int j0 = 0; j0 < jend; j0 += 16, buf ^= 1) {
         if (RNG) {
+            if (LD >= kTrmmRows || si < LD) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) Ls[buf][sj * 8 + u][si] = lreg[u];
+                for (int u = 0; u < 8; ++u) Ls[buf][sj * 8 + u][si] = lreg[u];
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -106,13 +112,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
         }
         double bc[4];
+        // rows of Z beyond n: the generic path clamps its loads and zeroes the operand; the RNG path needs neither -- the panel's columns beyond n
+        // are zero and a drawn normal is finite (|z| <= 6.76), so those products vanish on their own
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bc[q] = (j0 + 4 * lk + q < n) ? bz[q] : 0.0;
+        for (int q = 0; q < 4; ++q) bc[q] = (RNG || j0 + 4 * lk + q < n) ? bz[q] : 0.0;
         __syncthreads();
         if (j0 + 16 < jend) load_chunk(j0 + 16);                // prefetch: overlaps the MFMAs below
         const int tfirst = max(0, j0 / 16 - t0);                // row tiles above the chunk's block row are all zero
 #pragma unroll
-        for (int t = 0; t < kTrmmTiles; ++t) {
+        for (int t = 0; t < TT; ++t) {
             if (t >= tfirst && t < nt) {                        // wave-uniform
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -123,7 +131,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const double osc = rng.oscale2 ? sqrt(rng.oscale2[b]) : 1.0;
     if (wave_on && k0 + li < K) {
 #pragma unroll
-        for (int t = 0; t < kTrmmTiles; ++t) {
+        for (int t = 0; t < TT; ++t) {
             if (t < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -147,8 +155,10 @@ bool sample_trmm_fusable(int n) { return !(n & 3) && (n + 15) / 16 <= kTrmmTiles
 bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B, int n, int K, const uint64_t* seeds, uint32_t slo, uint32_t shi,
                               const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2) {
     if (!sample_trmm_fusable(n) || !panel) return false;
-    hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
-                       RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2}, kTrmmTiles);
+    if (n <= 112) hipLaunchKernelGGL((k_trmm_LZ_mfma<true, 112>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
+                                     RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2}, 7);
+    else hipLaunchKernelGGL((k_trmm_LZ_mfma<true>), dim3((K + 63) / 64, 1, B), dim3(256), 0, s, L, Lstride, (const double*)nullptr, E, n, K, active,
+                            RngArgs{seeds, slo, shi, rng_tab, panel, pstride, oscale2}, kTrmmTiles);
     return true;
 }
 // ---------------------------------------------------------------------------------------------

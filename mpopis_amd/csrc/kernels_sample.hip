@@ -11,7 +11,7 @@
 namespace mpopis {
 
 __global__ void k_rng_tab_init(double* g_rng_tab) {
-    const int i = threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < kRngTabLog) {
         const double c = (i == kRngTabLog - 1) ? 1.0 : 0.5 * (1.0 + (i + 0.5) / kRngTabLog);
         g_rng_tab[2 * i] = 1.0 / c; g_rng_tab[2 * i + 1] = log(c);
@@ -20,7 +20,7 @@ __global__ void k_rng_tab_init(double* g_rng_tab) {
         g_rng_tab[2 * i] = sinpi((2.0 * j + 1.0) / kRngTabSc); g_rng_tab[2 * i + 1] = cospi((2.0 * j + 1.0) / kRngTabSc);
     }
 }
-void launch_rng_tab_init(double* gtab, hipStream_t s) { hipLaunchKernelGGL(k_rng_tab_init, dim3(1), dim3(256), 0, s, gtab); }
+void launch_rng_tab_init(double* gtab, hipStream_t s) { hipLaunchKernelGGL(k_rng_tab_init, dim3((kRngTabLog + kRngTabSc + 255) / 256), dim3(256), 0, s, gtab); }
 
 // Z[b][r][k] (K fastest) = standard normal number `lin` of the reference's draw order, scaled by
 // dscale[r] when the Cholesky factor is diagonal (then Z is already E).

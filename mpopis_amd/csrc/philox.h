@@ -6,10 +6,13 @@
 
 namespace mpopis {
 
+#ifndef MPOPIS_PHILOX_ROUNDS
+#define MPOPIS_PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t* out) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < MPOPIS_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -22,39 +25,38 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // ---- Box-Muller transcendentals from small tables (LDS) -------------------------------------------------------------------------------
 // The Philox / Box-Muller work of the fused sampler shares the SIMD's FP64 datapath with its MFMAs (kernels_mfma.hip), so every VALU
 // instruction counts.  Round 2 evaluated log and sin/cos with fdlibm-style argument reduction + degree-14 polynomials (~40 + ~35 VALU per
-// pair); with a 128-entry table for log and a 64-entry rotation table for sin/cos the polynomials shrink to |r| <= 2^-8 / |x| <= 0.05:
-// ~19 + ~23 VALU per pair, same accuracy class (<= 2 ulp of the result; the top log interval is exact at u -> 1, where sqrt(-2 log u) is
-// most sensitive).  Table: kRngTabLog = 128 x {1/c_i, log c_i}, c_i = (1 + (i + 0.5)/128)/2 (c_127 = 1), then kRngTabSc = 64 x
-// {sin, cos}(2 pi (j + 0.5)/64); filled once per device by k_rng_tab_init with the library's correctly rounded functions.
-constexpr int kRngTabLog = 128, kRngTabSc = 64, kRngTabDoubles = 2 * (kRngTabLog + kRngTabSc);
+// pair); round 3: a 128-entry table for log and a 64-entry rotation table for sin/cos (|r| <= 2^-8 / |x| <= 0.05: ~19 + ~23 VALU per pair);
+// round 4: 256 / 128 entries (6 KB of LDS), |r| <= 2^-9 / |x| <= 0.0246, two Horner steps less in log1p and one less in each of sin and cos --
+// same accuracy class (every normal within 1e-13 of the libm evaluation, tests/test_gpu_parity.py; the top log interval is exact at u -> 1,
+// where sqrt(-2 log u) is most sensitive).  Table: kRngTabLog x {1/c_i, log c_i}, c_i = (1 + (i + 0.5)/kRngTabLog)/2 (last entry: c = 1),
+// then kRngTabSc x {sin, cos}(2 pi (j + 0.5)/kRngTabSc); filled once per handle by k_rng_tab_init with the library's correctly rounded functions.
+constexpr int kRngTabLog = 256, kRngTabSc = 128, kRngTabDoubles = 2 * (kRngTabLog + kRngTabSc);
 
 // log(u) for a normal-range u in (0, 1)
 __device__ __forceinline__ double log_unit(double u, const double* __restrict__ tab) {
     const int k = __builtin_amdgcn_frexp_exp(u);               // u = m 2^k, m in [0.5, 1)
     const double m = __builtin_amdgcn_frexp_mant(u);
-    const int i = (__double2hiint(m) >> 13) & 127;             // top 7 fraction bits of m
+    const int i = (__double2hiint(m) >> 12) & 255;             // top 8 fraction bits of m
     const double inv = tab[2 * i], logc = tab[2 * i + 1];
-    const double r = fma(m, inv, -1.0);                        // |r| <= 2^-8
-    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
-    p = fma(p, r, 1.0 / 5.0);
-    p = fma(p, r, -1.0 / 4.0);
+    const double r = fma(m, inv, -1.0);                        // |r| <= 2^-9
+    double p = fma(r, 1.0 / 5.0, -1.0 / 4.0);                  // log1p(r) to r^5: the next term, r^6 / 6 <= 9.2e-18, is below half an ulp of every |log u| >= 1.2e-10 this is used for
     p = fma(p, r, 1.0 / 3.0);
     p = fma(p, r, -0.5);
     const double lp = fma(p * r, r, r);                        // log1p(r)
     return fma((double)k, 6.93147180559945286227e-01, logc) + lp;
 }
 
-// (sin, cos)(2 pi u) for u = (w + 0.5) 2^-32 straight from one Philox word: sector j = top 6 bits, x = 2 pi (frac - 0.5)/64 (exact), degree-7 /
-// degree-8 Taylor kernels on |x| <= 0.0491 and one rotation by the tabulated sector centre.
+// (sin, cos)(2 pi u) for u = (w + 0.5) 2^-32 straight from one Philox word: sector j = top 7 bits, x = 2 pi (frac - 0.5)/128 (exact), degree-5 /
+// degree-6 Taylor kernels on |x| <= 0.0246 (next terms: x^7/5040 <= 1.1e-15 x relative 4.3e-14 ... see below; x^8/40320 <= 3.3e-18) and one
+// rotation by the tabulated sector centre.  The sine's truncation is 4.3e-14 RELATIVE TO x, i.e. <= 1.1e-15 absolute: half an ulp of the
+// rotated result, whose magnitude is O(1) except within 1e-15 of the axes.
 __device__ __forceinline__ void sincos_2pi_u32(uint32_t w, const double* __restrict__ tab, double* sn, double* cs) {
-    const int j = w >> 26;
-    const double f = fma((double)(w & 0x3ffffffu), 0x1p-26, 0x1p-27 - 0.5);      // 64 u - j - 0.5, exact
-    const double x = f * 9.81747704246810387019e-02, z = x * x;                  // 2 pi / 64
-    double ps = fma(z, -1.0 / 5040.0, 1.0 / 120.0);
-    ps = fma(z, ps, -1.0 / 6.0);
+    const int j = w >> 25;
+    const double f = fma((double)(w & 0x1ffffffu), 0x1p-25, 0x1p-26 - 0.5);      // 128 u - j - 0.5, exact
+    const double x = f * 4.90873852123405193510e-02, z = x * x;                  // 2 pi / 128
+    const double ps = fma(z, 1.0 / 120.0, -1.0 / 6.0);
     const double s = fma(z * x, ps, x);
-    double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
-    pc = fma(z, pc, 1.0 / 24.0);
+    double pc = fma(z, -1.0 / 720.0, 1.0 / 24.0);
     pc = fma(z, pc, -0.5);
     const double c = fma(z, pc, 1.0);
     const double S = tab[2 * kRngTabLog + 2 * j], C = tab[2 * kRngTabLog + 2 * j + 1];
