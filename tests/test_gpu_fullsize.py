@@ -124,6 +124,38 @@ def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
     eng.close()
 
 
+def test_C4_batch64_agrees_with_small_batches(eng_mod, track):
+    """C4 at the chip-filling batch the bench reports (64 resident 3-car :cmamppi trials): the automatic four-part schedule, the one-workgroup
+    Cholesky (k_potrf_global) and Lanczos kernels (B x G > CUs rules the clusters out), the one-wave 3-car rollout kernel instead of the two-wave
+    one, the bitonic instead of the chip-wide rank sort -- none of which the oracle-anchored C4 cases (B <= 2: cooperative kernels, two-wave
+    rollouts) reach.  Trials are independent and seeded per slot, so slots of the 64-slot handle must reproduce the same trials run in a 2-slot
+    handle: iteration counts exact, sort-derived quantities included (a CMA step through a different permutation would not agree to 1e-7)."""
+    K, T, N, B = 4096, 50, 10, 64
+    cov = np.tile([0.0625, 0.1], 3)
+    seeds = 20240000 + 1 + np.arange(B, dtype=np.uint64)
+    mk = lambda nb: eng_mod.Engine("car", 3, "cmamppi", K, T, batch=nb, lam=10.0, ais_its=N, elite_threshold=0.8, cma_sigma=0.75, cov=cov, track=track)
+    big = mk(B)
+    big.seed_slots(seeds)
+    ob = big.policy_step(None)
+    Ub, Sb = big.get_U(), big.get_Sigma()
+    big.close()
+    for pair in ((0, 63), (21, 42)):
+        small = mk(2)
+        small.seed_slots(seeds[list(pair)])
+        os_ = small.policy_step(None)
+        Us, Ss = small.get_U(), small.get_Sigma()
+        small.close()
+        idx = list(pair)
+        assert np.array_equal(ob["iters_run"][idx], os_["iters_run"]) and np.all(os_["iters_run"] == N)
+        assert np.max(np.abs(ob["control"][idx] - os_["control"])) < 1e-8
+        c1, c2 = ob["cost"][idx], os_["cost"]
+        rel = np.abs(c1 - c2) / np.maximum(1.0, np.abs(c2))
+        assert np.sum(rel > 1e-7) <= K // 500, int(np.sum(rel > 1e-7))      # (beyond the few standstill-chatter rollouts, as everywhere)
+        assert np.max(np.abs(ob["weights"][idx] - os_["weights"])) < 1e-7
+        assert np.max(np.abs(Ub[idx] - Us)) < 1e-8
+        assert np.max(np.abs(Sb.reshape(B, -1)[idx] - Ss.reshape(2, -1))) < 1e-8 * np.max(np.abs(Ss))
+
+
 @pytest.mark.parametrize("P,ncars", [(300, 1), (960, 1), (2048, 1), (960, 3), (203, 1), (221, 1), (222, 3), (231, 1)])
 def test_large_tracks_rollout_costs(eng_mod, oracle, P, ncars):
     """Track(infile; sample_factor = 1) has ~960 points (car_racing_tracks.jl:16-23; the default factor 20 gives 48): beyond ~230 points the
