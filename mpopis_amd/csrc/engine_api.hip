@@ -599,7 +599,7 @@ int mpopis_policy_call(mpopis_handle* h, const double* x, const int32_t* t, cons
     if (flags) hipLaunchKernelGGL(k_call_in, dim3((nmax + 255) / 256), dim3(256), 0, h->stream, db, h->d_x, h->d_U, h->d_t, h->d_done, nx, nu, B, flags);
     int rc = h->policy_step_enqueue(false);
     if (rc) return rc;
-    const int seq = ++h->call_seq;
+    const int seq = (int)(++h->call_seq);
     hipLaunchKernelGGL(k_call_out, dim3(1), dim3(256), 0, h->stream, db, h->d_control, h->d_U, h->d_status, h->d_iters,
                        h->coop_disabled ? (const int*)nullptr : h->d_coop_timeouts, B * as, nu, B, seq);
     if (cost) HIPCHK(h, hipMemcpyAsync(cost, h->d_cost, sizeof(double) * B * K, hipMemcpyDeviceToHost, h->stream));

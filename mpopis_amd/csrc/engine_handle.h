@@ -76,7 +76,7 @@ struct mpopis_handle {
     // from it, the last kernel writes (control, rolled U, status, iters, cooperative time-outs) straight into it: no copy commands, one wait.
     // doubles: in_x[B*ss] in_U[B*cs] out_control[B*as] out_U[B*cs]; then ints: in_t[B] in_done[B] out_status[B] out_iters[B] out_coop[1]
     double* h_call = nullptr; double* d_call = nullptr;   // host pointer / the same block as the device sees it
-    int call_seq = 0;                                     // sequence number the last k_call_out publishes (the host may spin on it)
+    unsigned call_seq = 0;                                // sequence number the last k_call_out publishes (the host may spin on it; wraps)
     // timing
     bool timing = false, ev_open = false; int timing_mask = ~0;
     // MPOPIS_DEBUG_LAUNCH=1: after every kernel class of a policy step, hipGetLastError + stream sync, so that a failing

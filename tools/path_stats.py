@@ -36,8 +36,8 @@ def point(tag, n):
     inv = lambda v: 1 - (1 - v) ** (1.0 / N)
     x = eng.get_state()[0]
     print("    rollouts that took the general sub-step %.4f, that end with Vx <= 0.5: %.4f" % (s[6] / max(1, s[0] // 500 * 64), s[7] / max(1, s[0] // 500 * 64)))
-    print("%-26s %.3f ms/step | sub-steps with a general lane %.4f | rewards through the general search %.4f (five-point tier %.4f) | per rollout (est.): general sub-step %.4f, 3-ring fails %.4f, 5-ring fails %.4f | slot0 Vx=%.1f" % (
-        tag, ms / n, s[1] / max(1, s[0]), s[4] / max(1, s[3]), s[5] / max(1, s[3]), inv((f & 1).astype(bool).mean()), inv((f & 2).astype(bool).mean()), inv((f & 4).astype(bool).mean()), x[0, 3]), flush=True)
+    print("%-26s %.3f ms/step | sub-steps with a general lane %.4f | rewards through the general search %.4f (five-point tier %.4f) | slot0 Vx=%.1f" % (
+        tag, ms / n, s[1] / max(1, s[0]), s[4] / max(1, s[3]), s[5] / max(1, s[3]), x[0, 3]), flush=True)
 
 
 if os.environ.get("FROZEN"):                                 # frozen-state policy steps after n closed-loop steps (what tools/midlap_bench.py times)
