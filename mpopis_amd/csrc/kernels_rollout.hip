@@ -490,9 +490,34 @@ __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, co
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; if (cmin) cmin[b] = ~0ull; }
     for (int i = tid; i < cs; i += 256) { const double u = U[(size_t)b * cs + i]; Uin[(size_t)b * cs + i] = u; Ucur[(size_t)b * cs + i] = u; }
-    if (x && tid < ncars) {
+    if (!x) return;
+    if (tid < ncars) {
         const size_t i = (size_t)b * ncars + tid;
-        write_xext(x + i * 8, xext + i * kCarExt, tk);
+        write_xext(x + i * 8, xext + i * kCarExt, Track{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr});      // (nearest point: below)
+    }
+    // the track point nearest to each car's start position -- the first minimum of |q_i|^2 - 2 q_i.p, exactly what within_track's full scan
+    // returns -- found by the whole workgroup (one thread scanning the track serially put 3-4 us on the critical path of EVERY MPC step: C2 0.130 -> 0.134 ms)
+    __shared__ double sh_v[4]; __shared__ int sh_i[4];
+    for (int c = 0; c < ncars; ++c) {
+        const double* s8 = x + ((size_t)b * ncars + c) * 8;
+        const double m2x = -2.0 * s8[0], m2y = -2.0 * s8[1];
+        double bv = 0.0; int bi = -1;
+        for (int i = tid; i < tk.P; i += 256) {
+            const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
+            if (bi < 0 || d < bv) { bv = d; bi = i; }                          // ascending i within a thread: its first minimum
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { sh_v[tid >> 6] = bv; sh_i[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) if (sh_i[w] >= 0 && (bi < 0 || sh_v[w] < bv || (sh_v[w] == bv && sh_i[w] < bi))) { bv = sh_v[w]; bi = sh_i[w]; }
+            xext[((size_t)b * ncars + c) * kCarExt + 12] = (double)bi;
+        }
     }
 }
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
