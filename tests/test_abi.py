@@ -29,6 +29,14 @@ def test_abi_version(L):
     assert L.mpopis_abi_version() == 3      # include/mpopis.h "ABI history"
 
 
+def test_null_handle_is_an_argument_error(L):
+    """every entry point that takes a handle refuses NULL with MPOPIS_ERR_ARG instead of crashing (no GPU needed)"""
+    assert L.mpopis_policy_call(None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.mpopis_policy_step(None, None, None, None, None, None, None, None) == -1
+    assert L.mpopis_set_state(None, None, None, None) == -1 and L.mpopis_get_U(None, None) == -1
+    assert L.mpopis_seed(None, 1) == -1 and L.mpopis_reset(None) == -1 and L.mpopis_set_overlap(None, 2) == -1
+
+
 def test_config_struct_layout():
     from mpopis_amd._lib import Config
     # 10 int32 + 5 double + uint64 = 40 + 40 + 8
