@@ -661,7 +661,9 @@ int mpopis_timing_enable(mpopis_handle* h, int32_t on) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
     if (on && h->events.empty()) {
         h->events.resize(2 * 8192);
-        for (auto& e : h->events) HIPCHK(h, hipEventCreate(&e));
+        // timing events carry no system-scope fence: a default event makes the queue write back / invalidate the caches at every record, which
+        // costs the kernels around it (measured in the bench's timed region: two records per rollout launch, ~1 % of the step)
+        for (auto& e : h->events) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     }
     h->timing = on != 0;
     h->timing_mask = (on == 1 || on == 0) ? ~0 : (on >> 1);     // 1: every class; otherwise bit (class + 1) selects a class
