@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpopis_hip.so")
+# MPOPIS_HIP_LIB: load another build of the library (julia/MPOPISHip.jl honours the same variable).  The A/B scripts under tools/ab/ point it
+# at a variant build instead of overwriting the product binary.
+LIB_PATH = os.environ.get("MPOPIS_HIP_LIB") or os.path.join(_HERE, "lib", "libmpopis_hip.so")
 
 ENV_MOUNTAINCAR, ENV_CAR, ENV_CARTPOLE = 0, 1, 2
 ENV_IDS = {"mountaincar": ENV_MOUNTAINCAR, "car": ENV_CAR, "cartpole": ENV_CARTPOLE}
@@ -58,8 +60,8 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise ImportError("libmpopis_hip.so not built: run `python -m mpopis_amd.build` "
-                              "(the engine has no CPU fallback)")
+            raise ImportError("%s not found: run `python -m mpopis_amd.build`%s (the engine has no CPU fallback)"
+                              % (LIB_PATH, " or unset MPOPIS_HIP_LIB" if os.environ.get("MPOPIS_HIP_LIB") else ""))
         L = C.CDLL(LIB_PATH)
         H = C.c_void_p
         L.mpopis_abi_version.restype = C.c_int

@@ -98,6 +98,7 @@ struct Track {           // env.track.{x′,y′,lane_width′} (+ n2[i] = x′[
 };
 constexpr int kRingPad = 3;          // a nearest point up to two ring steps from the anchor, plus its own ring neighbours
 constexpr int kTrackNbrW = 16;
+constexpr int kMaxTrackPoints = 2048;   // mpopis_set_track's limit (the rollout kernels stage 48 B per point in LDS)
 // Row i of nbr_dist has one spare slot (index nbrw): it holds ring_r2[i] = (1 - 1e-9) x the squared distance from q_i to the nearest
 // track point that is NOT one of its ring neighbours {i-1, i, i+1} (+inf when there is none).  If a position p satisfies
 // 4 |p - q_i|^2 < ring_r2[i], every non-ring point j is farther from p than q_i is (|p - q_j| >= |q_j - q_i| - |p - q_i| > |p - q_i|),
@@ -510,6 +511,12 @@ MP_HD bool track_project(double px, double py, double p1x, double p1y, double pm
 // previous call of the same rollout: with D = |p - q_anchor|, every point farther than 2D from q_anchor is farther
 // than D from p (triangle inequality), so only the first few entries of the anchor's neighbour list need scanning --
 // the result is the exact argmin (ties -> lowest index, like findmin), typically after 3-5 instead of P evaluations.
+// The search key of track point i for the position p (m2 = -2 p): v_i = |q_i|^2 - 2 q_i.p, and the order findmin imposes on (key, index) pairs --
+// smaller key first, ties to the lower index.  ONE definition for every place that looks for a nearest point (within_track's three scans, the
+// ring tiers' fall-back, k_step_begin's workgroup-wide scan for the start anchor): they must agree bit for bit.
+MP_HD double track_key(const double* x, const double* y, const double* n2, int i, double m2x, double m2y) { return fma(y[i], m2y, fma(x[i], m2x, n2[i])); }
+MP_HD bool track_key_before(double d, int j, double best, int mi) { return d < best || (d == best && j < mi); }
+
 MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out, int* anchor) {
     const double m2x = -2.0 * px, m2y = -2.0 * py;
     int mi = -1;
@@ -522,13 +529,13 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
         // ring candidates {a0-1, a0, a0+1}: all addresses known up front (one LDS round trip), no list indirection
         const int am = (a0 == 0) ? tk.P - 1 : a0 - 1, ap = (a0 == tk.P - 1) ? 0 : a0 + 1;
         const double x0 = tk.x[a0], y0 = tk.y[a0], xm = tk.x[am], ym = tk.y[am], xp = tk.x[ap], yp = tk.y[ap];
-        const double d0 = fma(y0, m2y, fma(x0, m2x, tk.n2[a0]));
+        const double d0 = track_key(tk.x, tk.y, tk.n2, a0, m2x, m2y);
         const double D02 = d0 + fma(px, px, py * py);                        // |p - q_a0|^2
         if (__builtin_expect(4.0 * D02 < tk.nbr_dist[a0 * S + tk.nbrw], 1)) {  // certified: no non-ring point can be nearer (see Track)
-            const double dm = fma(ym, m2y, fma(xm, m2x, tk.n2[am])), dp = fma(yp, m2y, fma(xp, m2x, tk.n2[ap]));
+            const double dm = track_key(tk.x, tk.y, tk.n2, am, m2x, m2y), dp = track_key(tk.x, tk.y, tk.n2, ap, m2x, m2y);
             mi = a0; best = d0;
-            if (dm < best || (dm == best && am < mi)) { best = dm; mi = am; }    // first minimum: ties -> lowest index, like findmin
-            if (dp < best || (dp == best && ap < mi)) { best = dp; mi = ap; }
+            if (track_key_before(dm, am, best, mi)) { best = dm; mi = am; }      // first minimum: ties -> lowest index, like findmin
+            if (track_key_before(dp, ap, best, mi)) { best = dp; mi = ap; }
             // the nearest point's own ring neighbours: two of the three are already here, the third is one more point
             const int e = (mi == am) ? ((am == 0) ? tk.P - 1 : am - 1) : ((ap == tk.P - 1) ? 0 : ap + 1);
             const double xe = tk.x[e], ye = tk.y[e];
@@ -544,18 +551,18 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
             for (int c = 1; c < tk.nbrw; ++c) {
                 if (tk.nbr_dist[a0 * S + c] >= bound) { closed = true; break; }
                 const int j = tk.nbr_idx[a0 * S + c];
-                const double d = fma(tk.y[j], m2y, fma(tk.x[j], m2x, tk.n2[j]));
-                if (d < best || (d == best && j < mi)) { best = d; mi = j; }
+                const double d = track_key(tk.x, tk.y, tk.n2, j, m2x, m2y);
+                if (track_key_before(d, j, best, mi)) { best = d; mi = j; }
             }
             if (__builtin_expect(!closed && tk.nbrw < tk.P, 0)) mi = -1;   // list exhausted before the bound: full scan
         }
     }
     if (__builtin_expect(mi < 0, 0)) {
         mi = 0;
-        best = fma(tk.y[0], m2y, fma(tk.x[0], m2x, tk.n2[0]));
+        best = track_key(tk.x, tk.y, tk.n2, 0, m2x, m2y);
 #pragma unroll 8
-        for (int i = 1; i < tk.P; ++i) {                                       // first minimum
-            const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
+        for (int i = 1; i < tk.P; ++i) {                                       // first minimum (ascending i: track_key_before without its tie clause)
+            const double d = track_key(tk.x, tk.y, tk.n2, i, m2x, m2y);
             mi = (d < best) ? i : mi;
             best = fmin(best, d);
         }

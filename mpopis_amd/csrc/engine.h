@@ -113,8 +113,9 @@ __device__ __forceinline__ void status_raise(int* p, int code) {
 
 void launch_rollout(const RolloutArgs& a, hipStream_t s);
 void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStream_t s, const Track& tk);
+// (iters_acc: per-slot running sum of the iteration counts of earlier steps, folded in before iters is cleared; may be null)
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk, unsigned long long* iters_acc = nullptr);
 
 // compute_weights (utils.jl:79-86) per slot: w = exp(-(1/λ)(c-min c)) / Σ
 void launch_weights(const double* cost, double* w, int B, int K, double lambda, const int* active,

@@ -28,6 +28,7 @@ static std::string g_create_error;
     } while (0)
 
 #include "engine_handle.h"
+#include "philox.h"
 #include <chrono>
 #include <atomic>
 
@@ -114,6 +115,20 @@ static hipError_t wait_stream(hipStream_t s) {
     }
     return hipStreamSynchronize(s);
 }
+// The per-MPC-step waits (mpopis_policy_step / mpopis_policy_call) know how long the previous step took: the spin only pays for sub-millisecond
+// steps (C2 0.15 ms, where the blocking wake-up is a quarter of the call); a handle whose last wait exceeded kSpinWorthMs (C3 1.8 ms, C4 5-25 ms, the
+// 64-trial batches) blocks right away instead of burning a host core for 3 ms first -- the 20-50 us wake-up is then below 3 % of the step.
+constexpr double kSpinWorthMs = 1.0;
+static bool wait_should_spin(const mpopis_handle* h) { return h->wait_est_ms <= kSpinWorthMs; }
+static void wait_note(mpopis_handle* h, std::chrono::steady_clock::time_point t0) {
+    h->wait_est_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+static hipError_t wait_step(mpopis_handle* h) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = wait_should_spin(h) ? wait_stream(h->stream) : hipStreamSynchronize(h->stream);
+    wait_note(h, t0);
+    return e;
+}
 
 static int fold_status(mpopis_handle* h, const int* per_slot) {
     int st = 0;
@@ -127,7 +142,7 @@ static int fold_status(mpopis_handle* h, const int* per_slot) {
 static int sync_status(mpopis_handle* h) {
     HIPCHK(h, hipMemcpyAsync(h->h_status.data(), h->d_status, sizeof(int) * h->B, hipMemcpyDeviceToHost, h->stream));
     if (h->h_coop_timeouts && !h->coop_disabled) HIPCHK(h, hipMemcpyAsync(h->h_coop_timeouts, h->d_coop_timeouts, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, wait_stream(h->stream));
+    HIPCHK(h, wait_step(h));
     // a cluster gave up waiting for a partner (its slot was recomputed by the one-workgroup kernel in the same step, so the results are
     // complete): this device cannot keep the clusters co-resident right now -- stop using them for this handle instead of paying the wait again
     if (h->h_coop_timeouts && *h->h_coop_timeouts > 0) h->coop_disabled = true;
@@ -221,8 +236,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_wn, (size_t)B * cs); rc |= dalloc(h, &h->d_mu, (size_t)B * cs); rc |= dalloc(h, &h->d_gvec, (size_t)B * cs);
     rc |= dalloc(h, &h->d_dscale, (size_t)B * cs); rc |= dalloc(h, &h->d_dscale0, (size_t)cs);
     rc |= dalloc(h, &h->d_control, (size_t)B * h->as); rc |= dalloc(h, &h->d_reward, B); rc |= dalloc(h, &h->d_wsum, B); rc |= dalloc(h, &h->d_cmin, B);
-    rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B);
-    rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, 2 * (256 + 128));      // philox.h: kRngTabDoubles
+    rc |= dalloc(h, &h->d_status, B); rc |= dalloc(h, &h->d_active, B); rc |= dalloc(h, &h->d_iters, B); rc |= dalloc(h, &h->d_iters_acc, B);
+    rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, mpopis::kRngTabDoubles);      // philox.h
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
@@ -304,7 +319,7 @@ int mpopis_set_env_params(mpopis_handle* h, const double* p, int32_t n) {
 }
 
 int mpopis_set_track(mpopis_handle* h, const double* x, const double* y, const double* w, int32_t P) {
-    if (!h || !x || !y || !w || P < 2 || P > 2048) { if (h) h->err = "bad track (need 2 <= P <= 2048 points)"; return MPOPIS_ERR_ARG; }
+    if (!h || !x || !y || !w || P < 2 || P > mpopis::kMaxTrackPoints) { if (h) h->err = "bad track (need 2 <= P <= 2048 points)"; return MPOPIS_ERR_ARG; }
     HIPCHK(h, hipSetDevice(h->cfg.device));
     double* d = nullptr;
     if (dalloc(h, &d, (size_t)4 * P)) return MPOPIS_ERR_HIP;
@@ -607,8 +622,9 @@ int mpopis_policy_call(mpopis_handle* h, const double* x, const int32_t* t, cons
     // Host wait.  Without bulk outputs everything the caller gets back sits in the mailbox, published by the sequence word: spin on that word
     // (coherent host memory; the store lands ~1-2 us after the kernel issues it) and leave the stream's completion signal alone -- the next call
     // is ordered behind this one by the stream anyway.  Every ~20 us the stream is queried so that a fault ends the wait; after 3 ms: block.
+    // Only when the previous step of this handle was short (wait_should_spin): a long step blocks from the start.
     static const int env_wait = [] { const char* e = getenv("MPOPIS_CALL_WAIT"); return e ? atoi(e) : 1; }();      // 0: runtime wait only (A/B)
-    if (env_wait && !cost && !weights) {
+    if (env_wait && !cost && !weights && wait_should_spin(h)) {
         const auto t0 = std::chrono::steady_clock::now();
         auto tq = t0;
         for (;;) {
@@ -623,8 +639,9 @@ int mpopis_policy_call(mpopis_handle* h, const double* x, const int32_t* t, cons
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        wait_note(h, t0);
     } else {
-        HIPCHK(h, wait_stream(h->stream));
+        HIPCHK(h, wait_step(h));
     }
     if (*hb.coop > 0) h->coop_disabled = true;
     if (control) memcpy(control, hb.control, sizeof(double) * B * as);
@@ -695,20 +712,29 @@ int mpopis_bench_policy_steps(mpopis_handle* h, int32_t steps, double* ms, doubl
     HIPCHK(h, hipSetDevice(h->cfg.device));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    // rollouts EXECUTED, not B * N * K: a CE / CMA iteration loop may break early (src/mppi_mpopi_policies.jl:458-461, :567-569).  k_step_begin folds
+    // every step's per-slot iteration count into d_iters_acc before clearing it; the last step's is still in d_iters when the region ends.
+    HIPCHK(h, hipMemsetAsync(h->d_iters_acc, 0, sizeof(unsigned long long) * h->B, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_iters, 0, sizeof(int) * h->B, h->stream));
     HIPCHK(h, wait_stream(h->stream));
     HIPCHK(h, hipEventRecord(e0, h->stream));
-    double rl = 0.0;
     for (int s = 0; s < steps; ++s) {
         int rc = h->policy_step_enqueue(false);
         if (rc) return rc;
-        rl += (double)h->B * h->N * h->K;     // upper bound; CE/CMA early breaks are reported via iters
     }
     HIPCHK(h, hipEventRecord(e1, h->stream));
     HIPCHK(h, hipEventSynchronize(e1));
     float t = 0.f;
     HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
     if (ms) *ms = t;
-    if (rollouts) *rollouts = rl;
+    if (rollouts) {
+        std::vector<unsigned long long> acc(h->B); std::vector<int> last(h->B);
+        HIPCHK(h, hipMemcpy(acc.data(), h->d_iters_acc, sizeof(unsigned long long) * h->B, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(last.data(), h->d_iters, sizeof(int) * h->B, hipMemcpyDeviceToHost));
+        double its = 0.0;
+        for (int b = 0; b < h->B; ++b) its += (double)acc[b] + (double)last[b];
+        *rollouts = its * h->K;
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int rc = sync_status(h);
     HIPCHK(h, hipGetLastError());
@@ -745,7 +771,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_Sig, nn); mv(d_L, nn); mv(d_tmpS, nn); mv(d_dscale, cs); mv(d_Lp, (ptrdiff_t)potrf_panel_doubles(cs));
     mv(d_Z, per); mv(d_E, per); mv(d_Zin, (ptrdiff_t)N * per); mv(d_cost, K); mv(d_w, K); mv(d_wsum, 1); mv(d_cmin, 1);
     mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
-    mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_seeds, 1);
+    mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_iters_acc, 1); mv(d_seeds, 1);
     mv(d_order, K); mv(d_resi, K); mv(d_alias, K); mv(d_residx_log, (ptrdiff_t)std::max(1, N - 1) * K); mv(d_resi_in, (ptrdiff_t)(N - 1) * K);
     mv(d_resu, K); mv(d_accept, K); mv(d_alias_need, 1); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
@@ -807,7 +833,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     const bool sigma_fixed = (pol == MPOPIS_POL_MPPI || pol == MPOPIS_POL_GMPPI || pol == MPOPIS_POL_IMPPI || pol == MPOPIS_POL_MUAISMPPI);
     // status / active / iters reset, U_orig = pol.U (d_Uin keeps U_orig; d_Ucur is the rebinding pol.U inside the loop), extended start states
     launch_step_begin(status_sticky ? nullptr : d_status, d_active, alive_gate, d_iters, d_U, d_Uin, d_Ucur, B, cs,
-                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream, weights_in_moments ? d_cmin : nullptr, env.track);
+                      env.kind == MPOPIS_ENV_CAR ? d_x : nullptr, d_xext, env.ncars, stream, weights_in_moments ? d_cmin : nullptr, env.track, d_iters_acc);
     if (!sigma_fixed) hipLaunchKernelGGL(k_bcast_f64, dim3((nn + 255) / 256), dim3(256), 0, stream, d_Sigma0, d_Sig, nn, B);   // Σ′ = pol.Σ
     if (pol == MPOPIS_POL_CMAMPPI) cma_begin();
     // Shapes the fused sampler does not cover (cs > 128: Z goes through memory anyway) with device RNG, a dense proposal from iteration 2 on

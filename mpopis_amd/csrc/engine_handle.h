@@ -39,6 +39,7 @@ struct mpopis_handle {
     double* d_wsum = nullptr;          // [B] Σ_k w_k of the last k_weights launch of the AIS loop
     double *d_wn = nullptr, *d_mu = nullptr, *d_gvec = nullptr, *d_control = nullptr, *d_reward = nullptr, *d_traj = nullptr;
     int *d_status = nullptr, *d_active = nullptr, *d_iters = nullptr;
+    unsigned long long* d_iters_acc = nullptr;   // per slot: AIS iterations executed by the policy steps BEFORE the last one (k_step_begin folds iters in before clearing it)
     uint64_t* d_seeds = nullptr;
     double* d_rng_tab = nullptr;            // Box-Muller tables (philox.h), filled at creation
     // elite selection / resampling
@@ -76,6 +77,7 @@ struct mpopis_handle {
     // from it, the last kernel writes (control, rolled U, status, iters, cooperative time-outs) straight into it: no copy commands, one wait.
     // doubles: in_x[B*ss] in_U[B*cs] out_control[B*as] out_U[B*cs]; then ints: in_t[B] in_done[B] out_status[B] out_iters[B] out_coop[1]
     double* h_call = nullptr; double* d_call = nullptr;   // host pointer / the same block as the device sees it
+    double wait_est_ms = 0.0;                             // how long the last synchronous per-step wait took (0: unknown): long steps block instead of spinning
     unsigned call_seq = 0;                                // sequence number the last k_call_out publishes (the host may spin on it; wraps)
     // timing
     bool timing = false, ev_open = false; int timing_mask = ~0;

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // (no cross-lane redistribution).  The LDS panel stores column c in row (c & 3) * 4 + (c >> 2), so that the A-operand
     // reads keep their conflict-free pattern Ls[4q + lk][..].
     auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4lk+q of the stream
-        // (rows beyond n draw from counters past the sample's range; their operands are zeroed below)
+        // (rows beyond n draw from counters past the sample's range: finite normals that meet the panel's zero columns beyond n, so nothing is zeroed here)
         const int kk = min(k0 + li, K - 1);
         philox_normal_quad(seed, rng.slo, rng.shi, ((uint64_t)kk * n + j0 + 4 * lk) >> 2, sh_tab, bz);             // (4 | n: sample_trmm_fusable)
     };

@@ -486,9 +486,12 @@ void launch_extend_state(const double* x, double* xext, int B, int ncars, hipStr
 // status = 0 (unless sticky), active = alive gate (or 1), iters = 0, U_orig = the loop's pol.U = pol.U, and the car start states extended
 // with sin/cos of psi / delta (as k_extend_state).
 __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur,
-                                                    int cs, const double* x, double* xext, int ncars, unsigned long long* cmin, Track tk) {
+                                                    int cs, const double* x, double* xext, int ncars, unsigned long long* cmin, Track tk, unsigned long long* iters_acc) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) { if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; if (cmin) cmin[b] = ~0ull; }
+    if (tid == 0) {
+        if (iters_acc) iters_acc[b] += (unsigned long long)iters[b];          // the previous step's executed iterations (CE / CMA early breaks counted as run)
+        if (status) status[b] = 0; active[b] = alive ? alive[b] : 1; iters[b] = 0; if (cmin) cmin[b] = ~0ull;
+    }
     for (int i = tid; i < cs; i += 256) { const double u = U[(size_t)b * cs + i]; Uin[(size_t)b * cs + i] = u; Ucur[(size_t)b * cs + i] = u; }
     if (!x) return;
     if (tid < ncars) {
@@ -503,36 +506,41 @@ __global__ void __launch_bounds__(256) k_step_begin(int* status, int* active, co
         const double m2x = -2.0 * s8[0], m2y = -2.0 * s8[1];
         double bv = 0.0; int bi = -1;
         for (int i = tid; i < tk.P; i += 256) {
-            const double d = fma(tk.y[i], m2y, fma(tk.x[i], m2x, tk.n2[i]));
-            if (bi < 0 || d < bv) { bv = d; bi = i; }                          // ascending i within a thread: its first minimum
+            const double d = track_key(tk.x, tk.y, tk.n2, i, m2x, m2y);        // the same key and order as within_track (car_dynamics.h)
+            if (bi < 0 || track_key_before(d, i, bv, bi)) { bv = d; bi = i; }  // ascending i within a thread: its first minimum
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            if (oi >= 0 && (bi < 0 || track_key_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
         }
         __syncthreads();
         if ((tid & 63) == 0) { sh_v[tid >> 6] = bv; sh_i[tid >> 6] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w) if (sh_i[w] >= 0 && (bi < 0 || sh_v[w] < bv || (sh_v[w] == bv && sh_i[w] < bi))) { bv = sh_v[w]; bi = sh_i[w]; }
+            for (int w = 1; w < 4; ++w) if (sh_i[w] >= 0 && (bi < 0 || track_key_before(sh_v[w], sh_i[w], bv, bi))) { bv = sh_v[w]; bi = sh_i[w]; }
             xext[((size_t)b * ncars + c) * kCarExt + 12] = (double)bi;
         }
     }
 }
 void launch_step_begin(int* status, int* active, const int* alive, int* iters, const double* U, double* Uin, double* Ucur, int B, int cs,
-                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk) {
-    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin, tk);
+                       const double* x, double* xext, int ncars, hipStream_t st, unsigned long long* cmin, const Track& tk, unsigned long long* iters_acc) {
+    hipLaunchKernelGGL(k_step_begin, dim3(B), dim3(256), 0, st, status, active, alive, iters, U, Uin, Ucur, cs, x, xext, ncars, cmin, tk, iters_acc);
 }
 
 // Dynamic LDS a rollout kernel may request without raising its limit: the default 64 KB minus the kernels' STATIC LDS (two-wave kernels:
-// mailbox 4 KB + control-cost column 0.5 KB + flags + per-car bounds, ~4.7 KB).  Beyond it the limit is raised (96 KB) before the launch.
+// mailbox 4 KB + control-cost column 0.5 KB + flags + per-car bounds, ~4.7 KB).  Beyond it the limit is raised before the launch, once per
+// kernel and device, to what the largest supported track needs: the ring-only layout at kMaxTrackPoints (48 P + 192 B = 98 496 B at P = 2048)
+// plus the static part, rounded up -- 112 KB of the CU's 160 KB.
 constexpr size_t kRolloutDynLdsDefault = 56 * 1024;
+constexpr int kRolloutDynLdsRaised = 112 * 1024;
+static_assert((size_t)(4 * (kMaxTrackPoints + 2 * kRingPad) + 2 * kMaxTrackPoints) * sizeof(double) + 8 * 1024 <= (size_t)kRolloutDynLdsRaised,
+              "ring table of the largest track + static LDS must fit the raised limit");
 // one `seen` mask per kernel (non-type template parameter): large tracks need the dynamic-LDS limit raised, per device
 template <void (*KERNEL)(RolloutArgs)>
 static void launch_rollout_kernel(dim3 grid, int block, size_t lds, hipStream_t st, const RolloutArgs& a) {
     static std::atomic<unsigned long long> seen{0};
-    if (lds > kRolloutDynLdsDefault) ensure_dyn_lds((const void*)KERNEL, 96 * 1024, seen);
+    if (lds > kRolloutDynLdsDefault) ensure_dyn_lds((const void*)KERNEL, kRolloutDynLdsRaised, seen);
     hipLaunchKernelGGL(KERNEL, grid, dim3(block), lds, st, a);
 }
 
@@ -547,7 +555,7 @@ void launch_rollout(const RolloutArgs& a, hipStream_t st) {
     }
     const int P = a.env.track.P, W = a.env.track.nbrw;
     // every table in LDS when that fits the default 64 KB (all bundled tracks: 48-60 points); larger tracks (Track(infile; sample_factor = 1):
-    // ~1000 points) stage the ring table only (<= 82 KB at the 2048-point limit: the kernels' dynamic-LDS limit is raised to 96 KB once)
+    // ~1000 points) stage the ring table only (48 P + 192 B: 96.2 KB at the 2048-point limit; the kernels' dynamic-LDS limit is raised to 112 KB once)
     const bool tl = track_lds_bytes(P, W, true) <= kRolloutDynLdsDefault;      // (static LDS of the two-wave kernels counted: P = 221, 222 used to total 65.7-66 KB without the limit being raised)
     const size_t lds = track_lds_bytes(P, W, tl);
     // small K: one sample-wave per workgroup keeps every wave on its own CU; large K: 4 waves share the LDS tables

@@ -39,7 +39,7 @@ __device__ __forceinline__ double log_unit(double u, const double* __restrict__ 
     const int i = (__double2hiint(m) >> 12) & 255;             // top 8 fraction bits of m
     const double inv = tab[2 * i], logc = tab[2 * i + 1];
     const double r = fma(m, inv, -1.0);                        // |r| <= 2^-9
-    double p = fma(r, 1.0 / 5.0, -1.0 / 4.0);                  // log1p(r) to r^5: the next term, r^6 / 6 <= 9.2e-18, is below half an ulp of every |log u| >= 1.2e-10 this is used for
+    double p = fma(r, 1.0 / 5.0, -1.0 / 4.0);                  // log1p(r) to r^5: the next term is r^6 / 6 <= 9.2e-18 ABSOLUTE -- below half an ulp of |log u| except in the top interval (c = 1, log u = log1p(r) itself), where it is up to ~20 ulp at the far end (|log u| ~ 2e-3); harmless at the 1e-13 the normals are tested to
     p = fma(p, r, 1.0 / 3.0);
     p = fma(p, r, -0.5);
     const double lp = fma(p * r, r, r);                        // log1p(r)

@@ -245,16 +245,20 @@ def test_plain_c_client_gives_the_same_numbers_as_the_python_mirror(M, tmp_path)
 def test_policy_call_equals_the_four_call_composition(M):
     """mpopis_policy_call (one host wait, mailbox in pinned mapped memory) against set_state + set_U + policy_step + get_U on a twin handle:
     controls, rolled U, costs, weights and iters bit-identical over a short closed loop; car env, 3 slots, :μΣaismppi and :cemppi;
+    a third handle takes the same loop with want_cost = False (the mailbox-spin wait instead of the stream wait): same controls and U;
     x = None keeps the resident state; U = None rolls the resident pol.U."""
     from mpopis_amd import engine as eng_mod
     for pol, kw in (("μΣaismppi", {}), ("cemppi", dict(sigma_est="ss", elite_threshold=0.8)), ("gmppi", {})):
         mk = lambda: eng_mod.Engine("car", 1, pol, 256, 20, batch=3, lam=10.0, alpha=1.0, ais_its=3, lam_ais=20.0, cov=[0.0625, 0.1], seed=41, **kw)
-        a, b = mk(), mk()
-        Ua, Ub = np.zeros((3, 40)), np.zeros((3, 40))
+        a, b, c = mk(), mk(), mk()
+        Ua, Ub, Uc = np.zeros((3, 40)), np.zeros((3, 40)), np.zeros((3, 40))
         for step in range(4):
             x, t, done = b.get_state()
             x[:, 3] += 0.25 * step                               # the host owns the state: hand over something the resident copy does not hold
             ra = a.policy_call(x, t, done, Ua, want_cost=True)   # Ua rolled in place
+            rc_ = c.policy_call(x, t, done, Uc, want_cost=False) # the production form: nothing but the mailbox comes back, the host spins on its sequence word
+            assert rc_["cost"] is None and np.array_equal(rc_["control"], ra["control"]) and np.array_equal(rc_["iters_run"], ra["iters_run"]), (pol, step)
+            assert np.array_equal(Uc, Ua), (pol, step)
             b.set_state(x, t, done); b.set_U(Ub)
             rb = b.policy_step(None)
             Ub = b.get_U()
@@ -271,7 +275,7 @@ def test_policy_call_equals_the_four_call_composition(M):
         assert np.array_equal(r1["control"], r2["control"]) and np.array_equal(a.get_U(), b.get_U())
         with pytest.raises(Exception):
             a.policy_call(None, [0, 0, 0], None)                 # t without x
-        a.close(); b.close()
+        a.close(); b.close(); c.close()
 
 
 def test_concurrent_handles_with_cooperative_kernels(M):

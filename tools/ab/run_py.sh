@@ -1,6 +1,4 @@
 #!/bin/bash
-# A/B two builds of libmpopis_hip.so on the SAME GPU box: runs `python <script> <args>` with tools/ab/libA.so, then libB.so, twice
+# A/B two builds of libmpopis_hip.so on the SAME GPU box: runs `python <script> <args>` with tools/ab/libA.so, then libB.so, twice (MPOPIS_HIP_LIB selects the build)
 cd "$(dirname "$0")/../.."
-cp mpopis_amd/lib/libmpopis_hip.so /tmp/lib_cur.so
-for rep in 1 2; do for v in A B; do cp tools/ab/lib$v.so mpopis_amd/lib/libmpopis_hip.so; echo "== $v"; python "$@" 2>&1 | tail -${TAILN:-4}; done; done
-cp /tmp/lib_cur.so mpopis_amd/lib/libmpopis_hip.so
+for rep in 1 2; do for v in ${VARIANTS:-A B}; do echo "== $v"; MPOPIS_HIP_LIB=$PWD/tools/ab/lib$v.so python "$@" 2>&1 | tail -${TAILN:-4}; done; done

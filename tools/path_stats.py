@@ -1,4 +1,4 @@
-"""dev: path counters of the rollout kernel (needs tools/ab/libstats.so, built by tools/path_stats.sh, copied over the library):
+"""dev: path counters of the rollout kernel (needs tools/ab/libstats.so, built by tools/path_stats.sh, selected with MPOPIS_HIP_LIB=tools/ab/libstats.so):
 share of sub-steps in which some lane of the wave took the general sub-step, share of reward evaluations through the general search,
 at the reset state and after n closed-loop MPC steps.   usage (GPU box): python tools/path_stats.py [trials] [policy] [K] [N] [cars]"""
 import ctypes as C, os, sys
