@@ -217,9 +217,11 @@ int  mpopis_gather_summary(mpopis_handle *h, const double *records, int32_t n_lo
 int  mpopis_comm_destroy(mpopis_handle *h);
 
 /* Execution knob.  A handle can split its batch into parts that run as independent chains on their own HIP streams, so that
- * the latency-bound links of one chain (Cholesky, weights) hide under another's rollouts: worth 1-3 % at >= 64 resident
- * K = 4096 trials, nothing below.  Default (on <= 0): one stream.  on = 1 or 2: two halves; 3, 4: that many parts.
- * Results do not depend on it (bit-identical per slot). */
+ * the latency-bound links of one chain (Cholesky, sort, alias table) and the tail of its rollout launch hide under another chain's
+ * throughput kernels: 5-30 % of an MPC step for the adaptive policies from ~48 resident K = 4096 trials on, nothing below.
+ * Default (on <= 0): the engine picks the measured optimum for the handle's shape (one stream for small batches and for :mppi / :gmppi).
+ * on = 1: one stream (what a per-kernel profile wants); 2..4: that many parts.  (Until round 4 the default was one stream and on = 1
+ * meant two halves.)  Results do not depend on it (bit-identical per slot). */
 int  mpopis_set_overlap(mpopis_handle *h, int32_t on);
 
 /* ---- measurement hooks (bench.py; HIP events on the engine's own stream) ----------------------- */

@@ -164,6 +164,23 @@ inline void build_track_ring(int P, const double* x, const double* y, const doub
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
+// all lanes / some lane of the wave (device); the single caller (host)
+MP_HD bool wave_all(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(v);
+#else
+    return v;
+#endif
+}
+MP_HD unsigned long long wave_ballot(bool v) {     // the lanes for which v holds, as a scalar mask (host: bit 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(v);
+#else
+    return v ? 1ull : 0ull;
+#endif
+}
+MP_HD bool wave_any(bool v) { return wave_ballot(v) != 0; }
+
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 MP_HD double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
 
@@ -259,15 +276,20 @@ MP_HD double fma_v(double a, double b, double c) {
 
 struct TireK { double fymax, thr, k2, k3; };
 
-MP_HD TireK tire_consts(double mufz, double Ca, double fxt) {                  // mufz = μ f_z
+// fy_max of an axle (:253) and, from it, the rest of the brush-model constants.  Two functions because the general sub-step only needs fy_max
+// while the tyre saturates (the usual state of a car that is not moving forward) -- the other three are functions of fy_max alone, so deriving them
+// on demand gives the same bits as deriving them up front.
+MP_HD double tire_fymax(double mufz, double fxt) { return fast_sqrt(fmax(fma(mufz, mufz, -(fxt * fxt)), 1e-8)); }   // mufz = μ f_z
+MP_HD TireK tire_from_fymax(double fymax, double Ca) {
     TireK k;
-    k.fymax = fast_sqrt(fmax(fma(mufz, mufz, -(fxt * fxt)), 1e-8));            // :253
+    k.fymax = fymax;
     const double rf = fast_rcp(k.fymax), rc = 1.0 / Ca;        // rc: Ca is wave-uniform
     k.thr = 3 * k.fymax * rc;                                  // tan of the switch angle :255
     k.k2 = ((Ca * Ca) * (1.0 / 3.0)) * rf;                     // C^2/(3 fy_max)
     k.k3 = ((Ca * Ca * Ca) * (1.0 / 27.0)) * (rf * rf);        // C^3/(27 fy_max^2)
     return k;
 }
+MP_HD TireK tire_consts(double mufz, double Ca, double fxt) { return tire_from_fymax(tire_fymax(mufz, fxt), Ca); }
 
 // Car state as the kernels carry it: the reference's 8 doubles plus sin/cos of psi and delta, which
 // are advanced by angle addition and never re-evaluated inside a rollout.
@@ -305,54 +327,17 @@ MP_HD double tire_poly(double ta, double Ca, const TireK& k) {
     return ta * fma(at, fma(-k.k3, at, k.k2), -Ca);
 }
 
-// One Euler sub-step for ANY sign of Vx (cold path of car_action_step; delta, sd, cd already advanced).
-//   rear : alpha_r = atan2(yr,Vx).  |alpha_r| < atan(T)  <=>  Vx > 0 and |yr/Vx| < T; tan(alpha_r) = yr/Vx;
-//          otherwise saturated with sign(alpha_r) = sign(yr) (atan2(0,0) = 0 gives fy = 0).
-//   front: alpha_f = atan2(yf,Vx) - delta is the angle of q = R(-delta)(Vx,yf) up to a 2pi wrap that can
-//          only occur when |alpha_f| > pi (saturated anyway).  Linear branch <=> q.x > 0 and |q.y/q.x| < T;
-//          saturated sign = sign(q.y) if q.x > 0 else sign(yf) (|alpha_f| >= pi/2 > |delta|).
-template <bool PSI>
-MP_HD void car_substep_general(const CarParams& p, double pedal, double sd, double cd,
-                               double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp) {
-    const double sg = jl_sign(Vx);
+// What the general sub-step needs of an action's forces for ONE value of sign(Vx) (:310-318): the axle drive / brake forces and the two fy_max.
+// They depend on (pedal, sign Vx) only, so a rollout kernel derives them once per action and sign instead of once per sub-step (2 square roots).
+struct AxleForces { double fxf, fxr, fymf, fymr; };
+MP_HD AxleForces car_axle_forces(const CarParams& p, double pedal, double sg) {
+    AxleForces a;
     const double fx = fma(p.Fxmax, fmax(pedal, 0.0), p.Fxmin * fmin(pedal, 0.0) * sg);     // :310-312
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
-    const double fxf = lam * fx, fxr = (1 - lam) * fx;
-    const TireK kf = tire_consts(fma(-p.mfz_f1, fx, p.mfz_f0), p.Caf, fxf);                  // :262-272 (same derived constants as the hot path)
-    const TireK kr = tire_consts(fma(p.mfz_r1, fx, p.mfz_r0), p.Car, fxr);
-    // :308 (CD1 |Vx| + CD0) sign(Vx).  The sign is applied by selection, not by a multiply: `fxr - t * sg` would be a product feeding a subtract,
-    // which -ffp-contract=fast fuses (harmlessly here, t * (+-1) is exact -- but the model code keeps no such pattern, see "Rounding discipline")
-    const double f_drag = fma(p.CD1, fabs(Vx), p.CD0);
-    const double fx_aero = (Vx > 0.0) ? f_drag : ((Vx < 0.0) ? -f_drag : f_drag * sg);
-    const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);
-    double fyr;
-    if (Vx > 0.0 && fabs(yr / Vx) < kr.thr) fyr = tire_poly(yr / Vx, p.Car, kr);
-    else fyr = (Vx == 0.0 && yr == 0.0) ? 0.0 : ((yr >= 0.0) ? -kr.fymax : kr.fymax);
-    double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));
-    if (Vx == 0.0 && yf == 0.0) { xq = cd; yq = -sd; }         // atan2(0,0) = 0 -> alpha_f = -delta
-    double fyf;
-    if (xq > 0.0 && fabs(yq / xq) < kf.thr) fyf = tire_poly(yq / xq, p.Caf, kf);
-    else fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -kf.fymax : kf.fymax;
-    // :322-328 with the same δt-folded constants as the hot path (k_rf = δt l_f/Izz, k_rr = δt l_r/Izz, k_v = δt/m)
-    const double flat = fma(fyf, cd, fxf * sd), flon = fma(fxf, cd, -(fyf * sd)), rd = r * p.ddt;
-    const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));
-    const double Vx1 = fma(p.k_v, flon + (fxr - fx_aero), fma(rd, Vy, Vx));
-    r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));
-    Vx = Vx1; Vy = Vy1;
-    double dpsi = r * p.ddt;
-    if (PSI) psi += dpsi;
-    int nrot = 1;
-    if (__builtin_expect(fabs(dpsi) > kTinyAngle, 0)) {        // |psi_dot| > 3.125 rad/s: split the rotation into <= 1/32 rad pieces
-        nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
-        dpsi = dpsi / nrot;
-        if (PSI) psi = fmod(psi, kTwoPi);
-    }
-    if (PSI) { if (psi > kPi) psi -= kTwoPi; else if (psi < -kPi) psi += kTwoPi; }
-    double sq, cq;
-    sincos_tiny(dpsi, &sq, &cq);
-    for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-    x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);
-    y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);
+    a.fxf = lam * fx; a.fxr = (1 - lam) * fx;
+    a.fymf = tire_fymax(fma(-p.mfz_f1, fx, p.mfz_f0), a.fxf);                                // :262-272 (same derived constants as the hot path)
+    a.fymr = tire_fymax(fma(p.mfz_r1, fx, p.mfz_r0), a.fxr);
+    return a;
 }
 
 // The action-only half of env(a): everything a model step needs that depends on the ACTION and the steering angle but not on the vehicle state
@@ -397,68 +382,107 @@ MP_HD void steer_rotate(double& sd, double& cd, double sdd, double cdd) {
     sd = s2; cd = c2;
 }
 
-// The state half of env(a): nsub Euler sub-steps (:299-333) of (x, y, psi, Vx, Vy, r) and (sin psi, cos psi) under the action constants k.  steer(sd, cd)
-// advances (sin delta, cos delta) by one sub-step -- a rotation in place, or a read of what another wave rotated.
-// Hot path (Vx > 0, front slip in the forward half plane): branch-free up to a rarely taken large-yaw-rate fix-up,
-// one shared reciprocal; everything else goes through car_substep_general.
-template <bool PSI, class SteerF>
-MP_HD void car_integrate(const CarParams& p, const ActionConsts& k, SteerF&& steer,
-                         double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp, double& sd, double& cd) {
-    const double pedal = k.pedal, fxf = k.fxf, fxr0 = k.fxr0;
-    const TireK kf = k.kf, kr = k.kr;
-    // carried across sub-steps: r δt (this sub-step's "old yaw rate x δt" is the previous one's dψ), and -- in rollouts, which read
-    // the position only after the action -- the position increments summed before the common factor δt is applied
-    double rdt = r * p.ddt, sx = 0.0, sy = 0.0;
-    auto substep = [&]() {
-        steer(sd, cd);                                                         // delta += dd :301
-        MPOPIS_STAT(0, 1);
-        const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);            // :304-305 numerators
-        const double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));  // (Vx, yf) rotated by -delta
-        if (__builtin_expect(!(Vx > 0.0 && xq > 0.0), 0)) {                    // cold: stopped / sliding backwards / NaN
-            MPOPIS_STAT(1, 1); MPOPIS_STAT(2, MPOPIS_STAT_LANES()); MPOPIS_SICK(1);
-            car_substep_general<PSI>(p, pedal, sd, cd, x, y, psi, Vx, Vy, r, sp, cp);
-            rdt = r * p.ddt;
-            return;
+// One Euler sub-step (:304-333; delta, sd, cd already advanced) for a lane in ANY state, as two halves: the tyre / axle forces by the lane's own
+// rules, and ONE integration tail for all lanes.
+//   HOT rules (Vx > 0 and the front slip in the forward half plane, xq > 0): branch-free, one shared reciprocal; the brush model is C1 at the
+//     switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259), so the cubic is evaluated at the clamped slip tangent.
+//   GENERAL rules (stopped, sliding backwards, NaN), forces for the lane's sign(Vx) derived on the spot:
+//     rear : alpha_r = atan2(yr,Vx).  |alpha_r| < atan(T)  <=>  Vx > 0 and |yr/Vx| < T; tan(alpha_r) = yr/Vx;
+//            otherwise saturated with sign(alpha_r) = sign(yr) (atan2(0,0) = 0 gives fy = 0).
+//     front: alpha_f = atan2(yf,Vx) - delta is the angle of q = R(-delta)(Vx,yf) up to a 2pi wrap that can only occur when |alpha_f| > pi
+//            (saturated anyway).  Linear branch <=> q.x > 0 and |q.y/q.x| < T; saturated sign = sign(q.y) if q.x > 0 else sign(yf).
+//     The switch tangent and the cubic's coefficients are derived from fy_max inside the linear branches only.
+// Why two halves: a rollout that brakes to a standstill flips between the two rule sets every sub-step for the rest of its horizon (the
+// reference's brake force flips with sign(Vx), :311) and takes its whole wave with it -- in a closed loop that is the usual state of a wave
+// (2-11 % of the rollouts of a call stop inside the horizon, i.e. nearly every wave of 64 holds one).  Such a wave executes hot forces + general
+// forces + one tail (~120 VALU) instead of two complete sub-steps (~160).  Round 5 measured the alternatives on the 64-trial headline workload
+// (one stream; reset state / closed loop / frozen at step 100, ms per step): two complete sub-steps 5.68 / 6.36 / 7.72; this form with the cold
+// lanes' position updated directly (a second divergent region) 5.76 / 6.30 / 7.26; a separate loop nest for waves with a slow lane, the
+// sign(Vx) = -1 forces derived once per action -- inlined: 6.16 / 6.81 / 7.94 (the allocator spills the next step's prefetched noise around the
+// whole action and copies five registers per trip), out of line (noinline, state through the stack): 6.47 / 8.51 / 14.3 (call ABI: 56 VGPR
+// spills in the caller).  rdt = r δt is carried across sub-steps (this sub-step's "old yaw rate x δt" is the previous one's dψ).
+template <bool PSI>
+MP_HD void car_substep(const CarParams& p, const ActionConsts& k, double sd, double cd,
+                              double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp, double& rdt, double& sx, double& sy) {
+    const double yf = fma(p.lf, r, Vy), yr = fma(-p.lr, r, Vy);                // :304-305 numerators
+    double xq = fma(Vx, cd, yf * sd), yq = fma(yf, cd, -(Vx * sd));            // (Vx, yf) rotated by -delta
+    const bool cold = !(Vx > 0.0 && xq > 0.0);
+    double fyr, flat, flon, frear;
+    if (__builtin_expect(cold, 0)) {                                           // stopped / sliding backwards / NaN
+        MPOPIS_STAT(1, 1); MPOPIS_STAT(2, MPOPIS_STAT_LANES()); MPOPIS_SICK(1);
+        const double sg = jl_sign(Vx);
+        const AxleForces a = car_axle_forces(p, k.pedal, sg);
+        const double f_drag = fma(p.CD1, fabs(Vx), p.CD0);
+        const double fx_aero = (Vx > 0.0) ? f_drag : ((Vx < 0.0) ? -f_drag : f_drag * sg);
+        fyr = (Vx == 0.0 && yr == 0.0) ? 0.0 : ((yr >= 0.0) ? -a.fymr : a.fymr);
+        if (Vx > 0.0) {
+            const TireK kr = tire_from_fymax(a.fymr, p.Car);
+            const double ta = yr / Vx;
+            if (fabs(ta) < kr.thr) fyr = tire_poly(ta, p.Car, kr);
         }
+        if (Vx == 0.0 && yf == 0.0) { xq = cd; yq = -sd; }     // atan2(0,0) = 0 -> alpha_f = -delta
+        double fyf = ((xq > 0.0 ? yq : yf) >= 0.0) ? -a.fymf : a.fymf;
+        if (xq > 0.0) {
+            const TireK kf = tire_from_fymax(a.fymf, p.Caf);
+            const double ta = yq / xq;
+            if (fabs(ta) < kf.thr) fyf = tire_poly(ta, p.Caf, kf);
+        }
+        flat = fma(fyf, cd, a.fxf * sd); flon = fma(a.fxf, cd, -(fyf * sd));
+        frear = a.fxr - fx_aero;
+    } else {
         const double rinv = fast_rcp1(Vx * xq);
         const double tar = yr * (rinv * xq), taf = yq * (rinv * Vx);           // tan(alpha_r), tan(alpha_f)
-        // the brush model is C1 at the switch angle and saturates at -fy_max sign(alpha) beyond it (:255-259): evaluating
-        // the cubic at the clamped tangent is the same function (the cubic at +-thr is -+fy_max up to rounding)
-        const double fyr = tire_poly(clamp_sym(tar, kr.thr), p.Car, kr);
-        const double fyf = tire_poly(clamp_sym(taf, kf.thr), p.Caf, kf);
-        const double flat = fma(fyf, cd, fxf * sd);                            // front axle force, lateral ...
-        const double flon = fma(fxf, cd, -(fyf * sd));                         // ... and longitudinal component
-        const double rd = rdt;                                                 // old yaw rate x δt
-        const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));                            // :323,:328
-        const double Vx1 = fma(p.k_v, flon + fma(-p.CD1, Vx, fxr0), fma(rd, Vy, Vx));           // :324,:327 (+ drag :308)
-        r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));                                            // :322,:326
-        Vx = Vx1; Vy = Vy1;
-        rdt = r * p.ddt;
-        const double dpsi = rdt;
-        if (PSI) psi += dpsi;                                                  // :329
-        double sq, cq;
-        sincos_tiny(dpsi, &sq, &cq);                           // valid for |dpsi| <= 1/32 ...
-        const double sp0 = sp, cp0 = cp;
-        { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-        if (__builtin_expect(fabs(dpsi) > kTinyAngle, 0)) {    // ... |psi_dot| > 3.125 rad/s (a spin): redo in pieces of <= 1/32 rad
-            const int nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
-            sincos_tiny(dpsi / nrot, &sq, &cq);
-            sp = sp0; cp = cp0;
-            for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
-            if (PSI) psi = fmod(psi, kTwoPi);
-        }
-        if (PSI) psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);                  // :330 atan(sin,cos)
-        if (PSI) {
-            x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                        // :331
-            y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                           // :332
-        } else {
-            sx = fma(Vx, cp, fma(-Vy, sp, sx));                                // Σ (Vx cos ψ - Vy sin ψ); x += δt Σ after the action
-            sy = fma(Vx, sp, fma(Vy, cp, sy));
-        }
-    };
+        fyr = tire_poly(clamp_sym(tar, k.kr.thr), p.Car, k.kr);
+        const double fyf = tire_poly(clamp_sym(taf, k.kf.thr), p.Caf, k.kf);
+        flat = fma(fyf, cd, k.fxf * sd); flon = fma(k.fxf, cd, -(fyf * sd));
+        frear = fma(-p.CD1, Vx, k.fxr0);
+    }
+    const double rd = rdt;                                                     // old yaw rate x δt
+    const double Vy1 = fma(p.k_v, flat + fyr, fma(-rd, Vx, Vy));               // :323,:328
+    const double Vx1 = fma(p.k_v, flon + frear, fma(rd, Vy, Vx));              // :324,:327 (+ drag :308)
+    r = fma(p.k_rf, flat, fma(-p.k_rr, fyr, r));                               // :322,:326
+    Vx = Vx1; Vy = Vy1;
+    rdt = r * p.ddt;
+    const double dpsi = rdt;
+    if (PSI) psi += dpsi;                                                      // :329
+    double sq, cq;
+    sincos_tiny(dpsi, &sq, &cq);
+    const double sp0 = sp, cp0 = cp;
+    { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+    if (__builtin_expect(fabs(dpsi) > kTinyAngle, 0)) {
+        const int nrot = (int)fmin(ceil(fabs(dpsi) * (1.0 / kTinyAngle)), 8192.0);
+        sincos_tiny(dpsi / nrot, &sq, &cq);
+        sp = sp0; cp = cp0;
+        for (int q = 0; q < nrot; ++q) { const double s2 = fma(sp, cq, cp * sq), c2 = fma(cp, cq, -(sp * sq)); sp = s2; cp = c2; }
+        if (PSI) psi = fmod(psi, kTwoPi);
+    }
+    if (PSI) psi -= (psi > kPi) ? kTwoPi : ((psi < -kPi) ? -kTwoPi : 0.0);     // :330 atan(sin,cos)
+    if (PSI) {
+        x = fma(fma(Vx, cp, -(Vy * sp)), p.ddt, x);                            // :331
+        y = fma(fma(Vx, sp, Vy * cp), p.ddt, y);                               // :332
+    } else {
+        sx = fma(Vx, cp, fma(-Vy, sp, sx));                                    // Σ (Vx cos ψ - Vy sin ψ); x += δt Σ after the action (every lane,
+        sy = fma(Vx, sp, fma(Vy, cp, sy));                                     // whichever force rules it went by: one more divergent region costs the hot path 2.5 %)
+    }
+}
+
+// The state half of env(a): nsub Euler sub-steps (:299-333) of (x, y, psi, Vx, Vy, r) and (sin psi, cos psi) under the action constants k;
+// (sdd, cdd) = sin / cos of the steering increment of a sub-step (delta += dd as a rotation of (sin delta, cos delta), :301).
+// Rollouts (PSI = false) read the position only after the action: the position increments are summed in (sx, sy) and the common factor δt is
+// applied once.
+template <bool PSI>
+MP_HD void car_integrate(const CarParams& p, const ActionConsts& k, double sdd, double cdd,
+                         double& x, double& y, double& psi, double& Vx, double& Vy, double& r, double& sp, double& cp, double& sd, double& cd) {
+    double rdt = r * p.ddt, sx = 0.0, sy = 0.0;
     for (int it = 0; it < p.nsub; it += 2) {                                   // two per trip: no loop-carried register copies
-        substep();
-        if (it + 1 < p.nsub) substep();                                        // (odd sub-step counts: wave-uniform branch)
+        steer_rotate(sd, cd, sdd, cdd);                                        // delta += dd :301
+        MPOPIS_STAT(0, 1);
+        car_substep<PSI>(p, k, sd, cd, x, y, psi, Vx, Vy, r, sp, cp, rdt, sx, sy);
+        if (it + 1 < p.nsub) {                                                 // (odd sub-step counts: wave-uniform branch)
+            steer_rotate(sd, cd, sdd, cdd);
+            MPOPIS_STAT(0, 1);
+            car_substep<PSI>(p, k, sd, cd, x, y, psi, Vx, Vy, r, sp, cp, rdt, sx, sy);
+        }
     }
     if (!PSI) { x = fma(sx, p.ddt, x); y = fma(sy, p.ddt, y); }
 }
@@ -476,7 +500,7 @@ MP_HD void car_action_step(const CarParams& p, CarState& c, double a0, double a1
     double dd, sdd, cdd;
     car_steer_step(p, a0, c.delta, &dd, &sdd, &cdd);
     const ActionConsts k = car_action_consts(p, a1);
-    car_integrate<PSI>(p, k, [&](double& s_, double& c_) { steer_rotate(s_, c_, sdd, cdd); }, x, y, psi, Vx, Vy, r, sp, cp, sd, cd);
+    car_integrate<PSI>(p, k, sdd, cdd, x, y, psi, Vx, Vy, r, sp, cp, sd, cd);
     // delta advanced nsub times by dd (:301); the loop above only consumes sin/cos(delta)
     double delta = c.delta;
     if (PSI) { for (int it = 0; it < p.nsub; ++it) delta += dd; }              // real env / logged states: literal summation
@@ -627,15 +651,6 @@ MP_HD int ring_wrap(int mi, int P) { return (mi < 0) ? mi + P : ((mi >= P) ? mi 
 MP_HD bool exceed_beta(const CarParams& p, double Vx, double Vy) {
     if (p.blim_acute) return (Vx > 0.0) ? (fabs(Vy) > p.tan_blim * Vx) : !(Vx == 0.0 && Vy == 0.0);
     return (Vx < 0.0) && (fabs(Vy) < p.tan_blim * (-Vx));
-}
-
-// all lanes of the wave agree (device) / the single caller (host)
-MP_HD bool wave_all(bool v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __all(v);
-#else
-    return v;
-#endif
 }
 
 MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y, double Vx, double Vy, int* anchor = nullptr) {

@@ -667,8 +667,8 @@ int mpopis_run_trials(mpopis_handle* h, int32_t num_steps, int32_t laps, double*
 int mpopis_set_overlap(mpopis_handle* h, int32_t on) {
     if (!h) return MPOPIS_ERR_ARG;
     if (h->split_pinned) return MPOPIS_OK;
-    if (on <= 0) { h->nsplit = 1; h->split_auto = true; return MPOPIS_OK; }                   // the default: one stream
-    h->nsplit = std::max(2, std::min((int)mpopis_handle::kMaxSplit, (int)on));               // 1, 2: two halves; 3, 4: that many parts
+    if (on <= 0) { h->nsplit = 1; h->split_auto = true; return MPOPIS_OK; }                   // the default: the engine picks (auto_parts)
+    h->nsplit = std::min((int)mpopis_handle::kMaxSplit, (int)on);                            // 1: one stream; 2..4: that many parts
     h->split_auto = false;
     return MPOPIS_OK;
 }
@@ -785,18 +785,38 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
 // their own streams, each started one sampler later than the previous: while one part sits in a latency-bound link of its chain
 // (Cholesky: nb workgroups on 256 CUs; weights; the scatter's finish), the other half's rollout / sampler fills the chip.
 // Per-slot results are bit-identical to the single-stream order (every kernel is slot-independent and deterministic).
+// How many part-chains the default schedule uses.  The chain of one AIS iteration (weights -> moments -> Cholesky -> sampler -> rollout) is
+// serial per trial, some links are latency-bound (Cholesky: B workgroups on 256 CUs; sort; alias table; finish kernels), and a rollout launch
+// that exactly fills the wave slots (64 K=4096-trials = 4096 waves on 4096 slots) leaves them emptying one by one at its tail.  Split into 2-4
+// skewed part-chains on their own streams, one part's latency-bound links and launch tails run under another part's throughput kernels.
+// Bit-identical per slot (every kernel is slot-independent and deterministic: tests/test_gpu_baseline_shapes.py).  The table is the
+// measured optimum (tools/split_sweep.py, one box, K = 4096 and 1024, 16..256 trials, ms per step at 1 / 2 / 3 / 4 parts), by rollout WAVES
+// in the batch (B x ceil(K / 64) for one car):
+//   :μΣaismppi  32 trials 3.37 / 4.07 / 3.80 / 4.24   48: 4.61 / 4.81 / 4.21 / 4.54   64: 5.72 / 5.75 / 5.63 / 5.36   96: 8.41 / 8.22 / 8.07 / 8.16   128: 10.7 all
+//   :cemppi     32: 5.45 / 5.26 / 5.04 / 5.12        48: 7.02 / 6.09 / 5.51 / 5.56   64: 8.78 / 7.79 / 6.94 / 6.66   128: 15.4 / 13.9 / 13.2 / 12.9
+//   :pmcmppi    32: 4.69 / 5.46 / 4.71 / 5.28        48: 6.34 / 5.47 / 5.41 / 5.38   64: 7.93 / 6.95 / 6.78 / 6.77   128: 14.7 / 13.3 / 12.8 / 12.6
+//   :μaismppi   16: 2.30 / 2.04 / 2.29 / 2.44        32: 3.16 / 2.80 / 2.93 / 3.17   64: 4.96 / 4.37 / 4.57 / 4.49   128: 9.27 / 8.55 / 8.91 / 8.91
+//   :gmppi      no gain at any size (one iteration: nothing to hide)
+// Below ~2000 waves every kernel of the chain is latency-bound and splitting only adds launches (and takes the two-wave rollout kernels
+// out of their regime).  :cmamppi with cs > 128 at >= 48 slots: the per-slot Cholesky / Lanczos kernels (one workgroup per slot: 64 of 256
+// CUs busy for ~540 us per iteration) go under the other parts' rollouts: C4 at 64 trials 28.6 -> 26.9 ms (32 trials: no gain).
+// mpopis_set_overlap(h, 1..4) overrides (1 = one stream: what a per-kernel profile wants).
+int mpopis_handle::auto_parts() const {
+    const int pol = cfg.policy;
+    if (pol == MPOPIS_POL_CMAMPPI) return (cs > 128 && B >= 48) ? 4 : 1;
+    if (N <= 1 || cs > 128 || env.kind != MPOPIS_ENV_CAR) return 1;           // one iteration / shapes outside the sweep: one stream
+    const long long waves = (long long)B * ((K + 63) / 64);
+    int np = 1;
+    if (pol == MPOPIS_POL_MUAISMPPI || pol == MPOPIS_POL_IMPPI) np = waves >= 1024 ? 2 : 1;
+    else if (pol == MPOPIS_POL_CEMPPI) np = waves >= 4096 ? 4 : (waves >= 2048 ? 3 : 1);
+    else if (pol == MPOPIS_POL_PMCMPPI) np = waves >= 3072 ? 4 : 1;
+    else if (pol == MPOPIS_POL_MUSIGMAAISMPPI) np = waves >= 4096 ? 4 : (waves >= 3072 ? 3 : 1);
+    return std::min(np, B);
+}
+
 int mpopis_handle::policy_step_enqueue(bool injected) {
     const int B0 = B;
-    // Default: ONE stream.  The multi-stream schedule (mpopis_set_overlap(h, 2..4): the batch as skewed part-chains on their own streams)
-    // hides the latency-bound links of one chain under the other chains' throughput kernels; since those links became short
-    // (Cholesky 61 -> 29 us) it is worth 1-3 % at >= 64 K=4096-trials and nothing below (ms per step at 1 / 2 / 3 / 4 parts: 32 trials
-    // 3.87 / 3.76 / 3.84 / 4.19, 64 trials 6.52 / 6.46 / 6.45 / 6.35, 128 trials 12.08 / 11.91 / 11.79 / 11.67), at the price of per-kernel
-    // durations that include time-sharing -- opt-in.
-    // Exception to the default: :cmamppi with cs > 128 at >= 48 resident slots.  There the per-slot Cholesky / Lanczos kernels (one workgroup
-    // per slot: 64 of 256 CUs busy for ~540 us per iteration) are 19 % of the step, and four part-chains put them under the other parts'
-    // rollouts: C4 at 64 trials 28.6 -> 26.9 ms per step (32 trials: no gain, 16.6 vs 16.9).
-    const int auto_np = (cfg.policy == MPOPIS_POL_CMAMPPI && cs > 128 && B0 >= 48) ? 4 : 1;
-    const int np = split_auto ? auto_np : std::min(nsplit, B0);
+    const int np = split_auto ? auto_parts() : std::min(nsplit, B0);
     if (np < 2) {
         side_free = (xstream[0] != nullptr);
         const int rc = step_enqueue_view(injected, nullptr, nullptr);

@@ -90,6 +90,7 @@ struct mpopis_handle {
     void time_end();
     void prepare_state();
     void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters = nullptr, int iter_n = 0);
+    int auto_parts() const;                               // part-chains of the default schedule for this handle's shape
     int policy_step_enqueue(bool injected);
     int step_enqueue_view(bool injected, hipEvent_t wait_first, hipEvent_t record_after_first_sampler);
     void shift_slots(ptrdiff_t db);                           // move every per-slot device pointer by db slots (slot views)

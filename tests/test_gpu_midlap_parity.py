@@ -8,13 +8,12 @@ the engine's own closed loop (mpopis_run_trials + mpopis_get_state / get_U at cl
 and at each one ONE pol(env) is compared: engine (device Philox stream) against the oracle fed the same stream, the same state and the same rolled
 pol.U -- K = 4096, H = 50, N = 10.
 
-Asserted: iterations equal, control <= 1e-5 (north star), rolled pol.U <= 1e-4, per-rollout cost outside the chatter class <= 1e-7 (:gmppi) / 1e-5
-(adaptive policies, see COST_TOL_CLEAN_AIS).  Reported (printed, and written to gpurun_out/midlap_parity.json when
+Asserted: iterations equal, control <= 1e-5 (north star), rolled pol.U <= 1e-4, per-rollout cost outside the chatter class <= 1e-7 on identical
+samples (COST_TOL_CLEAN).  Reported (printed, and written to gpurun_out/midlap_parity.json when
 that directory exists): per state the share of rollouts in the chatter class (oracle trajectory of the last iteration: min |Vx| < 0.12 m/s = one
 sub-step's full brake impulse), the number of per-rollout costs off by more than 1e-7 / 1e-5 and the largest, and the control / U deviations.
 The per-rollout cost bound of the north star (1e-5) cannot be promised for the chatter class -- for any pair of implementations -- so there the test
-counts instead of asserting.  MEASURED (round 5): in 118 harvested states, 0 costs off by more than 1e-5 anywhere,
-worst control deviation 1.6e-8.
+counts instead of asserting.  Measured bounds: INTEGRATION.md section 5.
 """
 import json
 import os
@@ -26,10 +25,11 @@ pytestmark = pytest.mark.gpu
 LAM, LAM_AIS = 10.0, 20.0
 T = 50
 CTRL_TOL, U_TOL = 1e-5, 1e-4
-# per-rollout cost outside the chatter class.  One iteration (:gmppi): both sides roll out the SAME samples -> 1e-7 as everywhere else.  Adaptive
-# policies: the last iteration's samples come from a proposal adapted on the earlier iterations' weights, chatter rollouts included, so the two
-# sides roll out samples ~1e-8 apart and the cost column compares neighbours, not twins: the north star's 1e-5.
-COST_TOL_CLEAN_1IT, COST_TOL_CLEAN_AIS = 1e-7, 1e-5
+# Per-rollout cost, outside the chatter class, ON THE SAME SAMPLES: the engine's final noise matrix E is handed to the oracle's simulate_model, so
+# both sides roll out identical controls (an adaptive policy's last proposal was adapted on the earlier iterations' weights, chatter rollouts
+# included; engine and oracle therefore DRAW samples ~1e-8 apart there, and comparing cost[k] of one with cost[k] of the other would compare
+# neighbours, not twins -- that looser figure is reported as `cost_vs_own_samples`).
+COST_TOL_CLEAN = 1e-7
 STALL_VX = 0.12
 
 
@@ -85,7 +85,7 @@ def compare_states(eng_mod, oracle, track, kind, ncars, K, N, states, seed, nthr
     try:
         eng.set_state(np.stack([s["x"] for s in states]))
         eng.set_U(np.stack([s["U"] for s in states]))
-        got = eng.policy_step(None)
+        got = eng.policy_step(None, want_E=True)
         U_dev = eng.get_U()
     finally:
         eng.close()
@@ -98,16 +98,17 @@ def compare_states(eng_mod, oracle, track, kind, ncars, K, N, states, seed, nthr
         Z = np.stack([oracle.philox_normals(seed + b + 1, 0, n, cs * K).reshape(K, cs) for n in range(N)])
         ref = pol(env, Z)
         assert ref["status"] == 0, (kind, s["step"], s["slot"], ref["status"])
-        _, traj = pol.simulate_model(U_orig, ref["E"], log=True)       # the last iteration's rollouts: V_k = U_orig + ref["E"][:, k]
-        vx = np.abs(traj.reshape(K, T, ncars, 8)[:, :, :, 3]).min(axis=(1, 2))
-        stalled = vx < STALL_VX
-        rel = np.abs(got["cost"][b] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)
+        rel_own = np.abs(got["cost"][b] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)      # each side on its own last-iteration samples
+        # the engine's samples through the oracle's model: E_out = E + (pol.U' - U_orig), so V_k = U_orig + E_out[:, k] (gamma = 0)
+        cost_same, traj_e = pol.simulate_model(U_orig, np.ascontiguousarray(got["E"][b].T), log=True)
+        stalled = np.abs(traj_e.reshape(K, T, ncars, 8)[:, :, :, 3]).min(axis=(1, 2)) < STALL_VX
+        rel = np.abs(got["cost"][b] - cost_same) / (np.abs(cost_same) + 1e-9)
         # ... and the FIRST iteration's (proposal = pol.Σ around the incoming pol.U: the widest spread of the call)
         _, traj1 = pol.simulate_model(U_orig, np.ascontiguousarray((Z[0] * np.sqrt(np.tile(cov, T))).T), log=True)
         stalled1 = np.abs(traj1.reshape(K, T, ncars, 8)[:, :, :, 3]).min(axis=(1, 2)) < STALL_VX
         rows.append(dict(policy=kind, cars=ncars, step=int(s["step"]), slot=int(s["slot"]), rolls=int(s.get("rolls", 0)), speed=float(np.hypot(s["x"][3], s["x"][4])),
                          chatter_share=float(stalled.mean()), chatter_share_first=float(stalled1.mean()), iters_dev=int(got["iters_run"][b]), iters_cpu=int(ref["iters_run"]),
-                         cost_gt_1e7=int((rel > 1e-7).sum()), cost_gt_1e5=int((rel > 1e-5).sum()), cost_max=float(rel.max()),
+                         cost_gt_1e7=int((rel > 1e-7).sum()), cost_gt_1e5=int((rel > 1e-5).sum()), cost_max=float(rel.max()), cost_vs_own_samples=float(rel_own.max()),
                          cost_max_clean=float(rel[~stalled].max()) if np.any(~stalled) else 0.0,
                          control=float(np.max(np.abs(got["control"][b] - ref["control"]))), U=float(np.max(np.abs(U_dev[b] - pol.U)))))
     return rows
@@ -123,7 +124,8 @@ def report(tag, rows):
     worst = dict(states=len(rows), chatter_share_max=max(max(r["chatter_share"], r["chatter_share_first"]) for r in rows),
                  chatter_share_mean=float(np.mean([r["chatter_share"] for r in rows])), chatter_share_first_mean=float(np.mean([r["chatter_share_first"] for r in rows])),
                  control=max(r["control"] for r in rows), U=max(r["U"] for r in rows), cost_clean=max(r["cost_max_clean"] for r in rows),
-                 cost_all=max(r["cost_max"] for r in rows), costs_off_1e5=sum(r["cost_gt_1e5"] for r in rows))
+                 cost_all=max(r["cost_max"] for r in rows), costs_off_1e5=sum(r["cost_gt_1e5"] for r in rows), costs_off_1e7=sum(r["cost_gt_1e7"] for r in rows),
+                 cost_vs_own_samples=max(r["cost_vs_own_samples"] for r in rows))
     print("  worst: " + " ".join("%s=%.3g" % kv for kv in worst.items()))
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
@@ -139,7 +141,7 @@ def check(rows):
         assert r["iters_dev"] == r["iters_cpu"], r
         assert r["control"] <= CTRL_TOL, r                              # the north star's bound, at the output that matters
         assert r["U"] <= U_TOL, r
-        assert r["cost_max_clean"] <= (COST_TOL_CLEAN_1IT if r["iters_cpu"] == 1 and r["policy"] == "gmppi" else COST_TOL_CLEAN_AIS), r
+        assert r["cost_max_clean"] <= COST_TOL_CLEAN, r                  # rollouts that never come near Vx = 0, same samples: tight, as everywhere else
 
 
 def test_C5_musigma_midlap_states(eng_mod, oracle, track):

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpopis_amd.engine import Engine
 eng = Engine("car", 1, "musigmaaismppi", 4096, 50, batch=64, lam=10.0, ais_its=10, lam_ais=20.0, cov=[0.0625, 0.1], seed=20240000)
-eng.set_overlap(0)
+eng.set_overlap(1)
 eng.bench_policy_steps(3)
 eng.timing_enable(2); eng.timing_reset()
 ms, rl = eng.bench_policy_steps(20)

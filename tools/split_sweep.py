@@ -11,7 +11,7 @@ for pol in pols:
     kw = dict(sigma_est="ss", elite_threshold=0.8) if pol == "cemppi" else {}
     for B in Bs:
         row = []
-        for ns in (0, 2, 3, 4):
+        for ns in (1, 2, 3, 4):
             eng = Engine("car", 1, pol, K, 50, batch=B, lam=10.0, ais_its=10, lam_ais=20.0, cov=[0.0625, 0.1], seed=20240000, **kw)
             eng.set_overlap(ns)
             eng.bench_policy_steps(10)
