@@ -482,10 +482,10 @@ def main():
 
     # Before the W warm-up steps: ~0.3 s of the same work, untimed, so that a fresh box has left its idle power state (clock ramp) and every
     # lazily loaded code object / LDS attribute is in place when the contract's warm-up starts.  Reported as config.prewarm_steps.
-    eng.timing_enable(2)                     # HIP events around the dominant (rollout) kernel only; created BEFORE the warm-up (16 k hipEventCreate calls
-    eng.bench_policy_steps(PREWARM_STEPS)    # take ~0.1 s of host time: with the GPU idle meanwhile the timed region used to start at a lower clock)
-    eng.bench_policy_steps(args.warmup)
-    eng.timing_reset()
+    eng.timing_enable(2)                     # HIP events (rollout kernel only) are used by the passes AFTER the timed region; created here, BEFORE the
+    eng.timing_enable(False)                 # warm-up (16 k hipEventCreate calls take ~0.1 s of host time: with the GPU idle meanwhile the timed
+    eng.bench_policy_steps(PREWARM_STEPS)    # region used to start at a lower clock).  The timed region itself records no events: in the default
+    eng.bench_policy_steps(args.warmup)      # schedule (four streams) two records per rollout launch cost ~2 % of the step.
     sync()
     t0 = time.perf_counter()
     ms_dev, rollouts = eng.bench_policy_steps(args.steps)
@@ -498,7 +498,6 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    tm = eng.timing_read()
     # R more repetitions of the same timed region (same bracketing), for the spread: median / min / max over R+1 samples.
     samples = [dt]
     for _ in range(max(0, args.repeats)):
@@ -512,9 +511,14 @@ def main():
         if dist is not None:
             dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         samples.append(float(tr.item()))
-    # Outside the timed region: the same workload on ONE stream (mpopis_set_overlap(h, 1)) -- every launch then has the chip to itself, which is
-    # what a per-kernel roofline figure and per-class kernel times need (in the default schedule for this shape, four part-chains time-share
-    # the chip and a launch's duration includes the other chains' kernels).
+    # Outside the timed region.  (1) The default schedule once more with HIP events around the rollout launches: how long a launch takes when the
+    # part-chains time-share the chip (roofline.default_schedule / frac_default_schedule).
+    eng.timing_enable(2); eng.timing_reset()
+    _, rl_def = eng.bench_policy_steps(args.steps)
+    tm = eng.timing_read()
+    eng.timing_enable(False)
+    # (2) The same workload on ONE stream (mpopis_set_overlap(h, 1)) -- every launch then has the chip to itself, which is what a per-kernel
+    # roofline figure and per-class kernel times need.
     eng.set_overlap(1)
     eng.bench_policy_steps(3)
     eng.timing_enable(2); eng.timing_reset()
@@ -594,7 +598,7 @@ def main():
         # chip with the other chains' kernels, so its duration is not a kernel-in-isolation figure)
         d_ms, d_n = tm["rollout"]
         d_avg_s = (d_ms / max(d_n, 1)) * 1e-3
-        d_per_launch = rollouts / max(d_n, 1)
+        d_per_launch = rl_def / max(d_n, 1)
         parts = max(1, round(d_n / max(1, args.steps * N_AIS)))
         # PMC-derived side fields: counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this same command,
         # tools/profile_round.sh); they come from profiles/pmc_rollout.json, which records the sha of the rollout kernel's sources it measured.
@@ -638,7 +642,7 @@ def main():
                                              "%.3f ms per step there; profiles/r05_bench_kernel_stats.csv is taken the same way" % (ms_one / args.steps),
                          "frac_default_schedule": d_per_launch * BYTES_PER_ROLLOUT / d_avg_s / 1e9 / HBM_PEAK_GBS,
                          "default_schedule": {"parts": parts, "rollout_avg_launch_us": d_avg_s * 1e6, "rollout_launches": d_n, "rollouts_per_launch": d_per_launch,
-                                              "what": "the timed region (`value`): the engine's default schedule for this shape = %d skewed part-chains on their own HIP streams; "
+                                              "what": "the schedule of the timed region (`value`), measured again with HIP events right after it: the engine's default for this shape = %d skewed part-chains on their own HIP streams; "
                                                       "a rollout launch covers 1/%d of the trials and time-shares the chip with the other chains' kernels" % (parts, parts)},
                          "one_stream": {"ms_per_step": ms_one / args.steps, "value": rl_one / (ms_one * 1e-3)},
                          "frac_definition": "contract formula: whole-path algorithmic bytes per launch (SURVEY 8d: %d B x rollouts per launch) / the dominant kernel's average launch time / 8 TB/s" % BYTES_PER_ROLLOUT,

@@ -20,7 +20,7 @@ def _free_port():
 def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--multi-stream", "--repeats", "3"]
+           "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--repeats", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -35,9 +35,14 @@ def test_bench_two_ranks_on_one_gpu():
     assert s["total_trials"] == 64 and s["trials_per_gpu"] == 32 and s["value"] > 0
     assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
     r = d["roofline"]
-    assert r["rollouts_per_launch"] * r["launches"] == 64 * 10 * 4096 * 2          # per-launch accounting matches the schedule
-    assert 0 < r["frac"] < 1 and r["launches"] == 2 * 10                      # default schedule: one launch per AIS iteration, all trials
-    assert r["multi_stream"]["ms_per_step"] > 0 and r["multi_stream"]["rollout_launches"] == 4 * 2 * 10      # --multi-stream pass
+    # roofline.frac: the one-stream isolation pass (three regions of 2 steps: one launch per AIS iteration, all 64 trials in it)
+    assert r["rollouts_per_launch"] == 64 * 4096 and r["launches"] == 3 * 2 * 10 and 0 < r["frac"] < 1 and "one-stream pass" in r["kernel_isolation"]
+    # the timed region's schedule: four part-chains for this shape, a launch covers a quarter of the trials
+    ds = r["default_schedule"]
+    assert ds["parts"] == 4 and ds["rollout_launches"] == 4 * 2 * 10 and ds["rollouts_per_launch"] == 16 * 4096
+    assert 0 < r["frac_default_schedule"] < r["frac"] and r["one_stream"]["ms_per_step"] > 0
+    assert "128 independent trials IN TOTAL" in d["config"]["workload"] and d["config"]["total_trials"] == 128
+    assert s["efficiency_vs_one_gpu"] > 0 and s["one_gpu_ms_per_step"] > 0
     assert "N = 1 only" in d["n1_only"] and "cpu_baseline" not in d and "configs" not in d
 
 

@@ -3,6 +3,7 @@ mean counter value per dispatch and mean duration.  Writes profiles/r04_pmc_summ
 profiles/pmc_rollout.json (HBM bytes per launch of the rollout kernel, used by bench.py)."""
 import csv, glob, hashlib, json, os, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "*", "pmc_counter_collection.csv")):
@@ -21,7 +22,7 @@ for k in sorted(acc, key=lambda k: -sum(dur[k])):
         row[c] = sum(v) / len(v) if v else ""
     rows.append(row)
 os.makedirs("profiles", exist_ok=True)
-with open("profiles/r04_pmc_summary.csv", "w", newline="") as fo:
+with open("profiles/%s_pmc_summary.csv" % tag, "w", newline="") as fo:
     w = csv.DictWriter(fo, fieldnames=["kernel", "dispatches_per_pass", "avg_us"] + names)
     w.writeheader()
     w.writerows(rows)

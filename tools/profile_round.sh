@@ -7,10 +7,16 @@ TAG=${1:-r01}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
-cd "$R" && python bench.py --multi-stream > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
+cd "$R" && python bench.py > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
 cd /tmp && export TMPDIR=/tmp
+# per-kernel durations need the chip to themselves: the profiled passes pin the schedule to ONE stream (MPOPIS_NSPLIT=1 = mpopis_set_overlap(h, 1),
+# what bench.py's own one-stream pass does for roofline.frac); the default schedule for this shape is four part-chains that time-share the chip.
+export MPOPIS_NSPLIT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-midlap --repeats 0 > "$O/prof_bench.log" 2>&1
 head -8 "$O"/prof/bench_kernel_stats.csv | cut -c1-160
+# ... and the default schedule once, for the record (durations include time-sharing)
+( unset MPOPIS_NSPLIT; rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_default" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-configs --no-midlap --repeats 0 > "$O/prof_bench_default.log" 2>&1 )
+rm -f "$O"/prof_default/*kernel_trace.csv
 for P in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU" \
          "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -20,6 +26,6 @@ for P in "FETCH_SIZE" "WRITE_SIZE" \
 done
 ls "$O"/pmc/*/ | head -20
 # summaries on the box (gpurun merges at most 64 MiB back): per-kernel PMC table + pmc_rollout.json next to the raw passes, then drop the per-dispatch dumps
-cd "$R" && python tools/pmc_summary.py "$O/pmc" > "$O/pmc_summary.log" 2>&1
-cp "$R"/profiles/r04_pmc_summary.csv "$R"/profiles/pmc_rollout.json "$O"/ 2>/dev/null
+cd "$R" && python tools/pmc_summary.py "$O/pmc" "$TAG" > "$O/pmc_summary.log" 2>&1
+cp "$R"/profiles/${TAG}_pmc_summary.csv "$R"/profiles/pmc_rollout.json "$O"/ 2>/dev/null
 rm -f "$O"/pmc/*/pmc_counter_collection.csv "$O"/pmc/*/pmc_kernel_trace.csv "$O"/prof/*kernel_trace.csv
