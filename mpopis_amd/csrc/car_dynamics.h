@@ -180,6 +180,21 @@ MP_HD unsigned long long wave_ballot(bool v) {     // the lanes for which v hold
 #endif
 }
 MP_HD bool wave_any(bool v) { return wave_ballot(v) != 0; }
+MP_HD bool wave_mask_full(unsigned long long m) {   // m covers every active lane (host: the single caller)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long ex = __builtin_amdgcn_read_exec();
+    return (m & ex) == ex;
+#else
+    return (m & 1ull) != 0;
+#endif
+}
+MP_HD int wave_lane() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)(threadIdx.x & 63);
+#else
+    return 0;
+#endif
+}
 
 MP_HD double jl_sign(double v) { return (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : v); }
 MP_HD double clampd(double v, double lo, double hi) { return v > hi ? hi : (v < lo ? lo : v); }
@@ -541,8 +556,7 @@ MP_HD bool track_project(double px, double py, double p1x, double p1y, double pm
 MP_HD double track_key(const double* x, const double* y, const double* n2, int i, double m2x, double m2y) { return fma(y[i], m2y, fma(x[i], m2x, n2[i])); }
 MP_HD bool track_key_before(double d, int j, double best, int mi) { return d < best || (d == best && j < mi); }
 
-MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out, int* anchor) {
-    const double m2x = -2.0 * px, m2y = -2.0 * py;
+MP_HD bool within_track_m2(const Track& tk, double px, double py, double m2x, double m2y, double* dist_out, int* anchor) {    // m2 = -2 p, from the caller
     int mi = -1;
     double best = 0.0;
     const int a0 = anchor ? *anchor : -1;
@@ -600,31 +614,40 @@ MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out,
     return track_project(px, py, p1x, p1y, pmx, pmy, ppx, ppy, tk.w[mi], dist_out);
 }
 
+MP_HD bool within_track(const Track& tk, double px, double py, double* dist_out, int* anchor) {
+    return within_track_m2(tk, px, py, -2.0 * px, -2.0 * py, dist_out, anchor);
+}
+
 // Straight-line fast path of the nearest-point search for the rollout kernels (anchor = the previous step's nearest point, ring table in LDS).
 // Applies when the anchor's certification holds (the nearest point is one of {a0-1, a0, a0+1}, see Track) and the three candidate distances
 // are pairwise different (no tie to break by index): then the argmin is two comparisons, its ring neighbours sit at fixed offsets of the padded
 // table, and no index arithmetic, list scan or point permutation is needed.  Returns false when it does not apply (first step, NaN position,
 // far from the anchor, exact ties): the caller then runs within_track, which finds the same point by the general rules -- and both end in
 // track_project, so the result never depends on the path taken.  rel (out) = nearest point - anchor in ring steps (-1, 0, +1).
-MP_HD bool ring_candidates(const double* ring, const double* cert, int a0, double px, double py, int* rel) {
+// (device: returns the wave mask of the lanes it applies to -- compares straight into scalar registers, ANDed there -- and the caller tests
+// "all lanes"; going through a per-lane bool and __all costs two more vector instructions per evaluation)
+MP_HD unsigned long long ring_candidates(const double* ring, const double* cert, int a0, double px, double py, double m2x, double m2y, int* rel) {
     const int a = a0 < 0 ? 0 : a0;                                             // branch-free: a missing anchor reads entry 0 and reports "not applicable"
     const double* e0 = ring + (size_t)4 * (a + kRingPad);
-    const double m2x = -2.0 * px, m2y = -2.0 * py;
     const double d0 = fma(e0[1], m2y, fma(e0[0], m2x, e0[2]));                 // |q|^2 - 2 q.p, as in within_track
     const double dm = fma(e0[-3], m2y, fma(e0[-4], m2x, e0[-2]));
     const double dp = fma(e0[5], m2y, fma(e0[4], m2x, e0[6]));
     const double D02 = d0 + fma(px, px, py * py);
-    const bool ok = (a0 >= 0) & (4.0 * D02 < cert[a]) & (d0 != dm) & (d0 != dp) & (dm != dp);
     *rel = (dm < d0 && dm < dp) ? -1 : ((dp < d0 && dp < dm) ? 1 : 0);
-    return ok;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // __builtin_amdgcn_[fs]cmp: LLVM predicate codes -- 38 = signed >, 4 = ordered <, 14 = unordered or != (C's != : true for NaN)
+    return __builtin_amdgcn_sicmp(a0, -1, 38) & __builtin_amdgcn_fcmp(4.0 * D02, cert[a], 4) & __builtin_amdgcn_fcmp(d0, dm, 14) &
+           __builtin_amdgcn_fcmp(d0, dp, 14) & __builtin_amdgcn_fcmp(dm, dp, 14);
+#else
+    return ((a0 >= 0) & (4.0 * D02 < cert[a]) & (d0 != dm) & (d0 != dp) & (dm != dp)) ? 1ull : 0ull;
+#endif
 }
 // Second tier, tried by a wave in which some lane failed the three-point test: five candidates {a0-2 .. a0+2} under the wider certificate
 // cert5 = ring_cert + P (see Track).  Applies when that certificate holds and the smallest of the five distances is attained ONCE (a tie would
 // have to be broken by track index, which the general search does).  rel (out) in -2 .. 2.
-MP_HD bool ring5_candidates(const double* ring, const double* cert5, int a0, double px, double py, int* rel) {
+MP_HD unsigned long long ring5_candidates(const double* ring, const double* cert5, int a0, double px, double py, double m2x, double m2y, int* rel) {   // (wave mask, like ring_candidates)
     const int a = a0 < 0 ? 0 : a0;
     const double* e0 = ring + (size_t)4 * (a + kRingPad);
-    const double m2x = -2.0 * px, m2y = -2.0 * py;
     const double d0 = fma(e0[1], m2y, fma(e0[0], m2x, e0[2]));
     const double dm = fma(e0[-3], m2y, fma(e0[-4], m2x, e0[-2]));
     const double dp = fma(e0[5], m2y, fma(e0[4], m2x, e0[6]));
@@ -638,7 +661,11 @@ MP_HD bool ring5_candidates(const double* ring, const double* cert5, int a0, dou
     if (dpp < best) { best = dpp; r = 2; }
     const int hits = (d0 == best) + (dm == best) + (dp == best) + (dmm == best) + (dpp == best);
     *rel = r;
-    return (a0 >= 0) & (4.0 * D02 < cert5[a]) & (hits == 1);                   // (a NaN position fails the certificate)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sicmp(a0, -1, 38) & __builtin_amdgcn_fcmp(4.0 * D02, cert5[a], 4) & __builtin_amdgcn_sicmp(hits, 1, 32);   // (a NaN position fails the certificate)
+#else
+    return ((a0 >= 0) & (4.0 * D02 < cert5[a]) & (hits == 1)) ? 1ull : 0ull;
+#endif
 }
 MP_HD bool ring_project(const double* ring, int a0, int rel, double px, double py, double* dist_out) {
     const double* e = ring + (size_t)4 * (a0 + rel + kRingPad);
@@ -659,7 +686,10 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
     int rel = 0;
     // rollout kernels (anchor carried, ring table staged): one wave-uniform branch -- every lane on the straight-line path, or the whole
     // wave through the general search (first step of a rollout, a lane far off its anchor, exact ties)
-    const bool fast = tk.ring && anchor && ring_candidates(tk.ring, tk.ring_cert, *anchor, x, y, &rel);
+    const double m2x = -2.0 * x, m2y = -2.0 * y;               // -2 p of the search key |q|^2 - 2 q.p: once, for whichever search runs
+    const unsigned long long fast_lanes = (tk.ring && anchor) ? ring_candidates(tk.ring, tk.ring_cert, *anchor, x, y, m2x, m2y, &rel) : 0ull;
+    const bool fast = (fast_lanes >> wave_lane()) & 1ull;      // (dev builds with MPOPIS_PATH_STATS only; dead otherwise)
+    (void)fast;
     MPOPIS_STAT(3, 1);
 #if defined(MPOPIS_PATH_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (tk.ring && anchor && *anchor >= 0 && !fast) {
@@ -671,17 +701,17 @@ MP_HD double car_reward(const CarParams& p, const Track& tk, double x, double y,
         if (!(4.0 * (dx_ * dx_ + dy_ * dy_) < r2_)) MPOPIS_SICK(4);
     }
 #endif
-    if (__builtin_expect(tk.ring && anchor && wave_all(fast), 1)) {
+    if (__builtin_expect(tk.ring && anchor && wave_mask_full(fast_lanes), 1)) {
         within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
         *anchor = ring_wrap(*anchor + rel, tk.P);
-    } else if (tk.ring && anchor && tk.P >= 5 && wave_all(ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, x, y, &rel))) {
+    } else if (tk.ring && anchor && tk.P >= 5 && wave_mask_full(ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, x, y, m2x, m2y, &rel))) {
         // some lane is farther from its anchor than the three-point certificate reaches (a car using the width of the road): five candidates, same tail
         MPOPIS_STAT(5, 1);
         within = ring_project(tk.ring, *anchor, rel, x, y, &dist);
         *anchor = ring_wrap(*anchor + rel, tk.P);
     } else {
         MPOPIS_STAT(4, 1);
-        within = within_track(tk, x, y, &dist, anchor);
+        within = within_track_m2(tk, x, y, m2x, m2y, &dist, anchor);
     }
     double rew = 0.0;
     if (!within) rew += -1000000.0;

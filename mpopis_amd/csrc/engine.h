@@ -186,7 +186,8 @@ bool launch_sample_trmm_fused(const double* L, size_t Lstride, double* E, int B,
                               const int* active, hipStream_t s, const double* rng_tab, const double* panel, size_t pstride, const double* oscale2 = nullptr);
 size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit);
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s,
+                      int B, int cs, int K, int ksplit, int sel_batch /* batch the kernel choice goes by: the handle's whole batch when this launch covers one part-chain of it (0: B; -1: compact form, see mpopis_handle::wcov_sel_batch) */,
+                      double den, double ridge, const int* active, hipStream_t s,
                       const double* rscale = nullptr, double* mu_out = nullptr, double* u_add = nullptr, const double* wsum = nullptr,
                       const double* cost = nullptr, unsigned long long* cmin = nullptr, double neg_inv_lambda = 0.0, const double* mu_shift = nullptr);
 bool wcov_weights_from_cost_ok(int cs, int K, int ksplit);

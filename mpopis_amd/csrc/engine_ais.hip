@@ -74,7 +74,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         }
         if (pol == MPOPIS_POL_MUSIGMAAISMPPI) {
             time_begin(4);
-            launch_wcov_mfma(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, 0.0, 10e-9, d_active, stream, nullptr,
+            launch_wcov_mfma(d_E, d_w, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), 0.0, 10e-9, d_active, stream, nullptr,
                              one_pass ? d_mu : nullptr, one_pass ? d_Ucur : nullptr, d_wsum,
                              fold ? d_cost : nullptr, fold ? d_cmin : nullptr, -1 / lam);        // one pass: also pol.U += μ′
             time_end();
@@ -103,13 +103,13 @@ int mpopis_handle::ais_update(int n, bool injected) {
             // (shifted by its first column -- d_gvec is free here: γ's row is rebuilt per iteration -- so that the one-pass moments do not cancel
             // when the resampled set collapses onto a few columns; the finish kernel adds the shift back to μ′)
             launch_gather_cols(d_E, d_order, d_Z, B, cs, K, d_active, stream, d_gvec);
-            launch_wcov_mfma(d_Z, nullptr, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream, nullptr,
+            launch_wcov_mfma(d_Z, nullptr, nullptr, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), (double)(K - 1), 10e-9, d_active, stream, nullptr,
                              d_mu, d_Ucur, nullptr, nullptr, nullptr, 0.0, d_gvec);            // also pol.U += μ′ (:809)
             time_end();
             return MPOPIS_OK;
         }
         launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, K, 1, d_active, stream);   // mean_and_cov(E[:,idx], 2): corrected
-        launch_wcov_mfma(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)(K - 1), 10e-9, d_active, stream);
+        launch_wcov_mfma(d_E, nullptr, d_order, K, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), (double)(K - 1), 10e-9, d_active, stream);
         time_end();
         hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);
         return MPOPIS_OK;
@@ -145,16 +145,16 @@ int mpopis_handle::ais_update(int n, bool injected) {
             time_begin(4);
             launch_gather_mean(d_E, d_order, nullptr, d_mu, B, cs, K, m_elite, 1, d_active, stream);
             if (cfg.sigma_est == MPOPIS_SIGMA_EST_RBLW || cfg.sigma_est == MPOPIS_SIGMA_EST_OAS) {   // DiagonalCommonVariance :421-423
-                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 0.0, d_active, stream);
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), (double)m_elite, 0.0, d_active, stream);
                 launch_common_shrink(d_Sig, B, cs, m_elite, cfg.sigma_est == MPOPIS_SIGMA_EST_OAS, 10e-9, d_active, stream);
             } else if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS || cfg.sigma_est == MPOPIS_SIGMA_EST_LW) {   // DiagonalUnequalVariance :417-419
-                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 0.0, d_active, stream);
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), (double)m_elite, 0.0, d_active, stream);
                 if (cfg.sigma_est == MPOPIS_SIGMA_EST_SS) launch_inv_sd(d_Sig, d_gvec, B, cs, d_active, stream);   // d_gvec is free here (γ row is rebuilt per iteration)
                 else launch_fill_f64(d_gvec, 1.0, (size_t)B * cs, stream);                       // :lw = same intensity on the unstandardised data
-                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_tmpS, d_part, B, cs, K, ksplit, 1.0, 0.0, d_active, stream, d_gvec);
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_tmpS, d_part, B, cs, K, ksplit, wcov_sel_batch(), 1.0, 0.0, d_active, stream, d_gvec);
                 launch_ss_shrink(d_Sig, d_tmpS, d_gvec, B, cs, m_elite, 10e-9, d_active, stream);
             } else {
-                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, (double)m_elite, 10e-9, d_active, stream);
+                launch_wcov_mfma(d_E, nullptr, d_order, m_elite, d_mu, d_Sig, d_part, B, cs, K, ksplit, wcov_sel_batch(), (double)m_elite, 10e-9, d_active, stream);
             }
             time_end();
             hipLaunchKernelGGL(k_add_active, dim3((cs + 255) / 256, B), dim3(256), 0, stream, d_mu, d_Ucur, cs, d_active);

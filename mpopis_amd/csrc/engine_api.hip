@@ -209,7 +209,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
 #undef CREATECHK
     if (const char* e = getenv("MPOPIS_DEBUG_LAUNCH")) h->debug_launch = atoi(e) != 0;
     if (const char* e = getenv("MPOPIS_NSPLIT")) { h->nsplit = std::max(1, std::min((int)mpopis_handle::kMaxSplit, atoi(e))); h->split_auto = false; h->split_pinned = true; }   // experiments / profiling: pins the schedule, mpopis_set_overlap is then ignored
-    h->B = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
+    h->B = cfg->batch; h->B_full = cfg->batch; h->K = cfg->num_samples; h->T = cfg->horizon;
     h->as = car ? 2 * cfg->num_cars : 1;
     h->ss = car ? 8 * cfg->num_cars : (cfg->env_kind == MPOPIS_ENV_CARTPOLE ? 4 : 2);
     h->cs = h->as * h->T;
@@ -803,6 +803,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
 // mpopis_set_overlap(h, 1..4) overrides (1 = one stream: what a per-kernel profile wants).
 int mpopis_handle::auto_parts() const {
     const int pol = cfg.policy;
+    const int B = B_full;                                                     // (the member B is a part's slot count while a part-chain is enqueued)
     if (pol == MPOPIS_POL_CMAMPPI) return (cs > 128 && B >= 48) ? 4 : 1;
     if (N <= 1 || cs > 128 || env.kind != MPOPIS_ENV_CAR) return 1;           // one iteration / shapes outside the sweep: one stream
     const long long waves = (long long)B * ((K + 63) / 64);

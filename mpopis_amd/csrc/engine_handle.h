@@ -90,6 +90,12 @@ struct mpopis_handle {
     void time_end();
     void prepare_state();
     void rollout(const double* Ucur, const double* Uorig, const double* gvec, const int* act, int* iters = nullptr, int iter_n = 0);
+    int B_full = 0;                                       // cfg.batch (B is narrowed to a part's slots while a part-chain is enqueued)
+    // What the scatter kernel's form goes by (launch_wcov_mfma): the whole batch -- or -1 = "the compact form" for shapes whose DEFAULT schedule is
+    // part-chains: the row form's 8-wave workgroups take a CU's whole LDS (136 KB), which a lone stream does not mind (74 vs 86 us at 64 trials) and
+    // concurrent chains do (no rollout / sampler workgroup fits beside one: the 64-trial step 5.64 instead of 5.35 ms).  A function of the shape
+    // only, never of the schedule actually running, so that a slot's bits do not depend on mpopis_set_overlap.
+    int wcov_sel_batch() const { return auto_parts() > 1 ? -1 : B_full; }
     int auto_parts() const;                               // part-chains of the default schedule for this handle's shape
     int policy_step_enqueue(bool injected);
     int step_enqueue_view(bool injected, hipEvent_t wait_first, hipEvent_t record_after_first_sampler);

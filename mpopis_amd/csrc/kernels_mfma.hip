@@ -572,7 +572,7 @@ size_t wcov_mfma_workspace_doubles(int B, int cs, int ksplit) {
 }
 bool wcov_mfma_can_emit_mean(int cs) { return (cs & 15) != 0; }      // needs a padding row for the ones
 void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int m, const double* mu, double* S, double* part,
-                      int B, int cs, int K, int ksplit, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
+                      int B, int cs, int K, int ksplit, int sel_batch, double den, double ridge, const int* active, hipStream_t s, const double* rscale,
                       double* mu_out, double* u_add, const double* wsum, const double* cost, unsigned long long* cmin, double neg_inv_lambda,
                       const double* mu_shift) {
     const int aug = (mu_out && !rscale && wcov_mfma_can_emit_mean(cs)) ? 1 : 0;   // mu_out: also produce μ = Σ w x / Σw (mu is then unused)
@@ -584,7 +584,9 @@ void launch_wcov_mfma(const double* X, const double* w, const int32_t* idx, int 
     static const int env_rows = [] { const char* e = getenv("MPOPIS_WCOV_ROWS"); return e ? atoi(e) : 1; }();
     // row form: 7 row tiles (kc == 64 then), an even number of partials, and enough 8-wave workgroups for most of the CUs (measured: wins from 16
     // resident C5 trials up -- 30 -> 28 us at 16, 86 -> 74 us at 64 -- and loses ~5 us at 8, where it fields 128 workgroups)
-    const bool rows = env_rows && nt == 7 && !rscale && !(ksplit & 1) && (long long)B * (ksplit / 2) >= (env_rows > 1 ? 1 : 192);
+    // The choice goes by the handle's WHOLE batch (sel_batch), not by this launch's share of it: the part-chains of a multi-stream schedule are in
+    // flight together, and a slot's result must not depend on the schedule (the two forms agree to rounding, not bit for bit).
+    const bool rows = env_rows && nt == 7 && !rscale && !(ksplit & 1) && sel_batch >= 0 && (long long)(sel_batch > 0 ? sel_batch : B) * (ksplit / 2) >= (env_rows > 1 ? 1 : 192);
     const size_t lds = ((size_t)nt * 16 * (rows ? 2 * kRowsS : kc + 1) + kc + (from_cost ? (rows ? 2 * per : per) : 0)) * sizeof(double);
     static std::atomic<unsigned long long> seen[5];
     ensure_dyn_lds((const void*)k_wcov_mfma_partial<64, false, true>, 160 * 1024, seen[4]);

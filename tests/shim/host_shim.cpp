@@ -49,10 +49,10 @@ extern "C" int shim_within_ring(int P, const double* tx, const double* ty, const
     static std::vector<double> n2; static Track tk; static const double* last = nullptr;
     if (last != tx) { tk = mk(P, tx, ty, tw, n2); last = tx; }
     int rel = 0;
-    bool ok = ring_candidates(tk.ring, tk.ring_cert, *anchor, px, py, &rel);
+    bool ok = ring_candidates(tk.ring, tk.ring_cert, *anchor, px, py, -2.0 * px, -2.0 * py, &rel);
     *fast = ok ? 1 : 0;
     if (!ok && tk.P >= 5) {                                    // second tier of car_reward: five candidates under the wider certificate
-        ok = ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, px, py, &rel);
+        ok = ring5_candidates(tk.ring, tk.ring_cert + tk.P, *anchor, px, py, -2.0 * px, -2.0 * py, &rel);
         if (ok) *fast = 2;
     }
     if (ok) {

@@ -102,6 +102,29 @@ def test_bench_batch_agrees_with_small_batches(eng_mod, track):
         assert np.max(np.abs(Sb.reshape(B, -1)[idx] - Ss.reshape(2, -1))) < 1e-9 * np.max(np.abs(Ss))
 
 
+@pytest.mark.parametrize("kind,K,B,kw", [("musigmaaismppi", 4096, 64, {}), ("cemppi", 4096, 48, dict(sigma_est="ss", elite_threshold=0.8)),
+                                         ("pmcmppi", 4096, 48, {}), ("muaismppi", 4096, 16, {}), ("musigmaaismppi", 1024, 256, {})])
+def test_default_schedule_is_bit_identical_to_one_stream_at_chip_filling_batches(eng_mod, track, kind, K, B, kw):
+    """From ~48 resident K = 4096 trials on the engine runs the adaptive policies as 2-4 skewed part-chains on their own streams by default
+    (mpopis_handle::auto_parts).  A slot's results must not depend on that: every kernel CHOICE goes by the handle's whole batch, not by the
+    part a launch covers (round 5 found the scatter kernel picking its row form by the launch's own batch: rounding-level differences between
+    the schedules at exactly the bench shape).  Default schedule vs mpopis_set_overlap(h, 1), two policy steps + a short closed loop: bitwise."""
+    outs = []
+    for overlap in (0, 1):
+        eng = eng_mod.Engine("car", 1, kind, K, 50, batch=B, lam=10.0, ais_its=10, lam_ais=20.0, cov=[0.0625, 0.1], track=track, seed=777, **kw)
+        eng.set_overlap(overlap)
+        res = []
+        for _ in range(2):
+            got = eng.policy_step(None)
+            res += [got["control"], got["cost"], got["weights"], got["iters_run"], eng.get_U()]
+        rec = eng.run_trials(3, 2)
+        res += [rec[:, :15], eng.get_state()[0], eng.get_U()]
+        eng.close()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_pmc_resampling_full_size_bit_exact(eng_mod, oracle, track):
     """Bit-exact resampling indices at K=4096 given identical weights and draws (alias table + sampling)."""
     K = 4096

@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     }
     float t = timeit([&] { launch_trmm_LZ_mfma(dL, nn, dZ, dE, B, cs, K, dact, s); }, 20, s);
     printf("trmm_mfma        %8.1f us  (%.1f TF half-counted)\n", t, (double)B * cs * cs * K / (t * 1e-6) / 1e12);
-    t = timeit([&] { launch_wcov_mfma(dZ, dw, nullptr, K, dmu, dS, dpart, B, cs, K, ksplit, 0.0, 1e-8, dact, s, nullptr); }, 20, s);
+    t = timeit([&] { launch_wcov_mfma(dZ, dw, nullptr, K, dmu, dS, dpart, B, cs, K, ksplit, 0, 0.0, 1e-8, dact, s, nullptr); }, 20, s);
     printf("wcov_mfma(+fin)  %8.1f us  (%.1f TF half-counted)\n", t, (double)B * cs * cs * K / (t * 1e-6) / 1e12);
     {
         std::vector<double> S(nn); CK(hipMemcpy(S.data(), dS, nn * 8, hipMemcpyDeviceToHost));
