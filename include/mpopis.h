@@ -39,8 +39,11 @@ extern "C" {
  * removed or changed in meaning); a caller that needs the newer entry points checks mpopis_abi_version() >= 2.
  * Error precedence when several slots / kernels fail in one call: MPOPIS_ERR_HIP > MPOPIS_ERR_ACTION > MPOPIS_ERR_NOT_PD > MPOPIS_ERR_NUMERIC --
  * the version-1 codes keep their order (numeric minimum) and are never hidden by MPOPIS_ERR_NUMERIC.
- * 3: + mpopis_policy_call (control = pol(env) with a single host wait).  Nothing removed or changed in meaning. */
-#define MPOPIS_ABI_VERSION 3
+ * 3: + mpopis_policy_call (control = pol(env) with a single host wait).  Nothing removed or changed in meaning.
+ * 4: no new entry point; the execution knob mpopis_set_overlap changed: the default (on <= 0) is now the engine's own choice of schedule for the
+ *    handle's shape instead of one stream, and on = 1 means "one stream" instead of "two halves".  Results never depended on the knob (bit-identical
+ *    per slot in every schedule), so a version-3 caller sees the same numbers, sooner. */
+#define MPOPIS_ABI_VERSION 4
 
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };
 

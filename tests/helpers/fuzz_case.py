@@ -31,6 +31,9 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
             e = O.OracleEnv("car", ncars, track=track)
             for _ in range(int(rng.integers(0, 30))):
                 e.step(np.clip(np.tile([0.05, 0.5], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
+            if rng.integers(0, 3) == 0:                        # a third of the slots: brake towards (or to) a standstill first -- the general force rules of
+                for _ in range(int(rng.integers(1, 16))):      # the sub-step and the reference's sign(Vx) chatter (src/envs/car_racing.jl:311) from the start state on
+                    e.step(np.clip(np.tile([0.0, -0.7], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
             envs.append(e)
             pols.append(O.OraclePolicy(kind, e, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0, elite_threshold=0.8,
                                        sigma_est=est, cma_sigma=0.75, nthreads=oracle_threads))
