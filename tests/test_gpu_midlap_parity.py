@@ -96,8 +96,16 @@ def compare_states(eng_mod, oracle, track, kind, ncars, K, N, states, seed, nthr
         pol.U = s["U"]
         U_orig = s["U"].copy()
         Z = np.stack([oracle.philox_normals(seed + b + 1, 0, n, cs * K).reshape(K, cs) for n in range(N)])
-        ref = pol(env, Z)
+        if kind == "pmcmppi":                                          # the alias sampler's (index, uniform) draws of the device stream (:805)
+            dd = [oracle.philox_resample_draws(seed + b + 1, 0, n | 0x80000000, K) for n in range(max(N - 1, 1))]
+            ref = pol(env, Z, np.array([d[0] for d in dd], dtype=np.int32), np.array([d[1] for d in dd]))
+        else:
+            ref = pol(env, Z)
         assert ref["status"] == 0, (kind, s["step"], s["slot"], ref["status"])
+        idx_equal = True
+        if kind == "pmcmppi" and ref["iters_run"] > 1:                 # resampling indices: bit-exact (north star), in mid-lap states too
+            n_it = int(ref["iters_run"])
+            idx_equal = bool(np.array_equal(got["res_idx0"][b][:n_it - 1], ref["res_idx0"][:n_it - 1]))
         rel_own = np.abs(got["cost"][b] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)      # each side on its own last-iteration samples
         # the engine's samples through the oracle's model: E_out = E + (pol.U' - U_orig), so V_k = U_orig + E_out[:, k] (gamma = 0)
         cost_same, traj_e = pol.simulate_model(U_orig, np.ascontiguousarray(got["E"][b].T), log=True)
@@ -110,7 +118,7 @@ def compare_states(eng_mod, oracle, track, kind, ncars, K, N, states, seed, nthr
                          chatter_share=float(stalled.mean()), chatter_share_first=float(stalled1.mean()), iters_dev=int(got["iters_run"][b]), iters_cpu=int(ref["iters_run"]),
                          cost_gt_1e7=int((rel > 1e-7).sum()), cost_gt_1e5=int((rel > 1e-5).sum()), cost_max=float(rel.max()), cost_vs_own_samples=float(rel_own.max()),
                          cost_max_clean=float(rel[~stalled].max()) if np.any(~stalled) else 0.0,
-                         control=float(np.max(np.abs(got["control"][b] - ref["control"]))), U=float(np.max(np.abs(U_dev[b] - pol.U)))))
+                         control=float(np.max(np.abs(got["control"][b] - ref["control"]))), U=float(np.max(np.abs(U_dev[b] - pol.U))), idx_equal=idx_equal))
     return rows
 
 
@@ -139,6 +147,7 @@ def report(tag, rows):
 def check(rows):
     for r in rows:
         assert r["iters_dev"] == r["iters_cpu"], r
+        assert r["idx_equal"], r                                        # :pmcmppi resampling indices, bit for bit
         assert r["control"] <= CTRL_TOL, r                              # the north star's bound, at the output that matters
         assert r["U"] <= U_TOL, r
         assert r["cost_max_clean"] <= COST_TOL_CLEAN, r                  # rollouts that never come near Vx = 0, same samples: tight, as everywhere else
@@ -197,4 +206,15 @@ def test_C4_cmamppi_3car_midlap_states(eng_mod, oracle, track):
     assert len(states) >= 3
     rows = compare_states(eng_mod, oracle, track, "cmamppi", 3, 4096, 10, states, seed + 500, nthreads=16, **kw)
     report("C4 3-car :cmamppi K=4096 N=10", rows)
+    check(rows)
+
+
+def test_pmcmppi_midlap_states_resampling_indices_bit_exact(eng_mod, oracle, track):
+    """:pmcmppi K=4096 N=10 at closed-loop steps 40 / 100 / 160 (4 trials): the alias table is built from weights that include chatter rollouts;
+    the resampled indices of all 9 resampling passes must still equal the oracle's, bit for bit (`bit-exact for resampling indices`)."""
+    seed = 20245000
+    states = harvest(eng_mod, track, "pmcmppi", 1, 4096, 10, 4, (40, 100, 160), seed)
+    assert len(states) >= 10
+    rows = compare_states(eng_mod, oracle, track, "pmcmppi", 1, 4096, 10, states, seed + 500)
+    report(":pmcmppi K=4096 N=10", rows)
     check(rows)
