@@ -36,7 +36,7 @@ inline void ensure_dyn_lds(const void* fn, int bytes, std::atomic<unsigned long 
 }
 
 // Wave issue priority (s_setprio 0..3, default 0): the latency-bound kernels of the per-slot chain raise it.  Whenever kernels of
-// different streams share the chip (the opt-in multi-stream schedule of policy_step_enqueue, the side chains of the CMA update, several
+// different streams share the chip (the part-chain schedule of policy_step_enqueue, the side chains of the CMA update, several
 // handles on one device), the short links then win the SIMD issue arbitration against long-running throughput waves instead of being
 // starved by them (measured: k_weights 9 us alone, 155 us next to a rollout kernel at equal priority).
 #define MPOPIS_HI_PRIO() __builtin_amdgcn_s_setprio(3)

@@ -7,9 +7,9 @@ struct mpopis_handle {
     int B = 0, K = 0, T = 0, as = 0, ss = 0, cs = 0, N = 1;
     double gamma = 0.0;
     hipStream_t stream = nullptr;
-    // Extra streams.  Opt-in multi-stream schedule (mpopis_set_overlap, policy_step_enqueue): the batch as 2..4 part-chains, the latency-bound
-    // links of one chain (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) under the others' throughput kernels.  In the default
-    // one-stream schedule the same streams carry side chains: ||L^-1||_F of the CMA update (xstream[0]) and the Z prefetch for cs > 128 (xstream[1])
+    // Extra streams.  Part-chain schedule (auto_parts / mpopis_set_overlap, policy_step_enqueue): the batch as 2..4 part-chains, the latency-bound
+    // links of one chain (Cholesky, weights, finish kernels: tens of workgroups on 256 CUs) under the others' throughput kernels.  When the batch
+    // runs as one chain the same streams carry side chains: ||L^-1||_F of the CMA update (xstream[0]) and the Z prefetch for cs > 128 (xstream[1])
     static constexpr int kMaxSplit = 4;
     hipStream_t xstream[kMaxSplit - 1] = {nullptr, nullptr, nullptr};          // streams of the 2nd .. 4th part
     bool split_pinned = false;   // MPOPIS_NSPLIT set: the schedule is fixed for the process
