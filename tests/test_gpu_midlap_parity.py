@@ -13,7 +13,7 @@ samples (COST_TOL_CLEAN).  Reported (printed, and written to gpurun_out/midlap_p
 that directory exists): per state the share of rollouts in the chatter class (oracle trajectory of the last iteration: min |Vx| < 0.12 m/s = one
 sub-step's full brake impulse), the number of per-rollout costs off by more than 1e-7 / 1e-5 and the largest, and the control / U deviations.
 The per-rollout cost bound of the north star (1e-5) cannot be promised for the chatter class -- for any pair of implementations -- so there the test
-counts instead of asserting.  Measured bounds: INTEGRATION.md section 5.
+counts instead of asserting.  Measured bounds: INTEGRATION.md section 6.
 """
 import json
 import os
