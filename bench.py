@@ -130,7 +130,7 @@ def midlap_agreement(x, U, device, slots=(0, 21, 42, 63), nthreads=16):
         got = eng.policy_step(None, want_E=True)
     finally:
         eng.close()
-    out = {"slots": slots, "control": 0.0, "cost_all_rollouts": 0.0, "costs_off_by_more_than_1e-5": 0, "iters_equal": True, "chatter_share": 0.0}
+    out = {"slots": slots, "control": 0.0, "oracle_vs_itself_control": 0.0, "cost_all_rollouts": 0.0, "costs_off_by_more_than_1e-5": 0, "iters_equal": True, "chatter_share": 0.0}
     for i, b in enumerate(slots):
         env = O.OracleEnv("car", CARS, track=O.load_track())
         env.state = x[b]
@@ -142,11 +142,18 @@ def midlap_agreement(x, U, device, slots=(0, 21, 42, 63), nthreads=16):
         cost_same, traj = pol.simulate_model(U_orig, np.ascontiguousarray(got["E"][i].T), log=True)
         rel = np.abs(got["cost"][i] - cost_same) / (np.abs(cost_same) + 1e-9)
         out["control"] = max(out["control"], float(np.max(np.abs(got["control"][i] - ref["control"]))))
+        # the calibration: the same oracle with pol.U nudged by 1e-13 relative -- how well conditioned the policy itself is at this state
+        env2 = O.OracleEnv("car", CARS, track=O.load_track())
+        env2.state = x[b]
+        pol2 = O.OraclePolicy("musigmaaismppi", env2, K, H, lam=LAM, U0=np.zeros(2 * CARS), cov=np.tile([0.0625, 0.1], CARS), N=N_AIS, lam_ais=LAM_AIS, nthreads=nthreads)
+        pol2.U = U[b] * (1.0 + 1e-13)
+        out["oracle_vs_itself_control"] = max(out["oracle_vs_itself_control"], float(np.max(np.abs(pol2(env2, Z)["control"] - ref["control"]))))
         out["cost_all_rollouts"] = max(out["cost_all_rollouts"], float(rel.max()))
         out["costs_off_by_more_than_1e-5"] += int((rel > 1e-5).sum())
         out["iters_equal"] = bool(out["iters_equal"] and int(got["iters_run"][i]) == int(ref["iters_run"]))
         out["chatter_share"] = max(out["chatter_share"], float((np.abs(traj.reshape(K, H, CARS, 8)[:, :, :, 3]).min(axis=(1, 2)) < 0.12).mean()))
     out["what"] = ("engine vs CPU oracle, one pol(env) from the state / pol.U of %d resident slots after the mid-lap block (device Philox stream on both sides): control = max |dev - cpu|; "
+                   "oracle_vs_itself_control = the oracle against the oracle with pol.U nudged by 1e-13 relative (the policy's own conditioning at these states); "
                    "cost = max relative per-rollout deviation over ALL K rollouts on identical samples (none set aside); tolerance of the north star: 1e-5" % len(slots))
     return out
 
