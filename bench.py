@@ -425,6 +425,14 @@ def main():
     eng = Engine("car", CARS, "μΣaismppi", K, H, batch=B, lam=LAM, alpha=1.0, ais_its=N_AIS, lam_ais=LAM_AIS,
                  cov=np.tile([0.0625, 0.1], CARS), seed=20240000 + rank * B, device=local_rank)
 
+    # torch's lazy CUDA initialisation (context, allocator, its own streams) out of the way NOW: left to the first torch.cuda.synchronize() -- the
+    # opening bracket of the timed region -- it overlaps the region's first steps and costs it 1.5 % (tools/first_sample.py: 5.35 vs 5.27 ms,
+    # the eleven regions behind it unaffected).  torch is plumbing here (barrier, all_reduce of the times); its start-up is not the workload.
+    # (Round 5 found the order to matter: HIP deals hardware queues to streams in creation order, and with torch initialised BEFORE the engine two of the
+    # four part-chain streams shared a queue: 6.85 instead of 5.3 ms per step.  The engine now probes and repairs that itself, verify_part_streams.)
+    torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
+
     def sync(barrier=True):
         # opening bracket: barrier + device sync.  Closing bracket: device sync only -- the all_reduce(MAX) of the per-rank times that follows
         # orders the ranks, so no collective's latency is charged to the timed region

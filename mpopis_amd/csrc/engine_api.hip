@@ -297,6 +297,7 @@ void mpopis_destroy(mpopis_handle* h) {
     for (auto e : h->events) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto st : h->xstream) if (st) (void)hipStreamDestroy(st);
+    for (auto st : h->rejected_streams) if (st) (void)hipStreamDestroy(st);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto e : h->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto e : h->ev_skew) if (e) (void)hipEventDestroy(e);
@@ -815,9 +816,49 @@ int mpopis_handle::auto_parts() const {
     return std::min(np, B);
 }
 
+// spin for `ticks` of the 100 MHz real-time counter (one wave)
+__global__ void k_spin_ticks(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+void mpopis_handle::verify_part_streams() {
+    part_streams_checked = true;
+    static const int env_check = [] { const char* e = getenv("MPOPIS_STREAM_CHECK"); return e ? atoi(e) : 1; }();
+    if (!env_check) return;
+    constexpr double kSpinUs = 200.0;
+    auto concurrent = [&](const std::vector<hipStream_t>& ss) {          // do one spin kernel per stream overlap?  (wall time of all of them < 1.6 spins)
+        for (auto s_ : ss) (void)hipStreamSynchronize(s_);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (auto s_ : ss) hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, s_, (unsigned long long)(kSpinUs * 100.0));
+        for (auto s_ : ss) (void)hipStreamSynchronize(s_);
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 1.6 * kSpinUs;
+    };
+    { std::vector<hipStream_t> warm{stream}; (void)concurrent(warm); }   // (first launch of the kernel: code object load)
+    std::vector<hipStream_t> chosen{stream};
+    int next_x = 0, created = 0;
+    while ((int)chosen.size() < kMaxSplit && created < 12) {
+        hipStream_t c = nullptr;
+        if (next_x < kMaxSplit - 1) c = xstream[next_x++];                 // the streams the handle was created with first
+        else { if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break; ++created; }
+        std::vector<hipStream_t> trial = chosen; trial.push_back(c);
+        if (concurrent(trial)) chosen.push_back(c); else rejected_streams.push_back(c);
+    }
+    // the chosen ones first (part-chains), then rejected ones as fillers: side chains (||L^-1||_F, Z prefetch) only need A stream
+    size_t r = 0;
+    for (int i = 0; i < kMaxSplit - 1; ++i) {
+        if (i + 1 < (int)chosen.size()) xstream[i] = chosen[i + 1];
+        else if (r < rejected_streams.size()) { xstream[i] = rejected_streams[r]; rejected_streams.erase(rejected_streams.begin() + r); }
+    }
+    max_parts = std::max(1, (int)chosen.size());
+    (void)hipGetLastError();
+}
+
 int mpopis_handle::policy_step_enqueue(bool injected) {
     const int B0 = B;
-    const int np = split_auto ? auto_parts() : std::min(nsplit, B0);
+    int np = split_auto ? auto_parts() : std::min(nsplit, B0);
+    if (np >= 2 && !part_streams_checked) verify_part_streams();
+    np = std::min(np, max_parts);
     if (np < 2) {
         side_free = (xstream[0] != nullptr);
         const int rc = step_enqueue_view(injected, nullptr, nullptr);

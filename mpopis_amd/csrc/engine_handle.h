@@ -96,6 +96,14 @@ struct mpopis_handle {
     // concurrent chains do (no rollout / sampler workgroup fits beside one: the 64-trial step 5.64 instead of 5.35 ms).  A function of the shape
     // only, never of the schedule actually running, so that a slot's bits do not depend on mpopis_set_overlap.
     int wcov_sel_batch() const { return auto_parts() > 1 ? -1 : B_full; }
+    // The part-chain streams must sit on DIFFERENT hardware queues: HIP deals its (by default four) queues to streams in creation order, whatever else
+    // the process has created before, and two chains that share a queue serialise (the same 64-trial step 6.8 instead of 5.3 ms when torch had
+    // initialised the device first).  Checked once, at the first multi-part step, with a 200-us spin kernel per stream (verify_part_streams); streams
+    // that share a queue with an earlier one are replaced, and max_parts says how many independent ones there are.
+    bool part_streams_checked = false;
+    int max_parts = kMaxSplit;
+    std::vector<hipStream_t> rejected_streams;            // (kept until the handle goes: destroying one would hand its queue to the next candidate)
+    void verify_part_streams();
     int auto_parts() const;                               // part-chains of the default schedule for this handle's shape
     int policy_step_enqueue(bool injected);
     int step_enqueue_view(bool injected, hipEvent_t wait_first, hipEvent_t record_after_first_sampler);
