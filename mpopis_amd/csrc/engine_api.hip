@@ -925,22 +925,6 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             Lp = d_L; Lstride = nn;
         }
         cur_L = Lp; cur_Lstride = Lstride; cur_L_scaled = cma_scaled && n > 1;
-        {
-            // :cmamppi: tr(Σ^-1) (= ||L^-1||_F², times σ² when L factors σ²Σ) of THIS iteration's update needs only the factor this iteration samples from -- start it now on the free
-            // second stream (low wave priority: it shares the chip with the sampler and the rollout, which at small batches leave most CUs idle), so
-            // that the Lanczos kernel of the update never waits for it.  It used to start behind the rollout, beside the sort, and part of it stayed on
-            // the critical path: C4 6.56 -> 5.98 ms per step at one trial, 8.25 -> 7.70 at 8, 11.2 -> 10.8 at 16, neutral from 32 on
-            // (MPOPIS_TRTRI_EARLY=0 restores the old placement for A/B runs).
-            static const int env_early = [] { const char* e = getenv("MPOPIS_TRTRI_EARLY"); return e ? atoi(e) : 1; }();
-            trtri_early = false;
-            if (env_early && pol == MPOPIS_POL_CMAMPPI && side_free && n < N) {
-                (void)hipEventRecord(ev_skew[2], stream);
-                (void)hipStreamWaitEvent(xstream[0], ev_skew[2], 0);
-                launch_trtri_fro(Lp, Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
-                (void)hipEventRecord(ev_join[0], xstream[0]);
-                trtri_early = true;
-            }
-        }
         if (gamma != 0.0) launch_chol_solve_gvec(Lp, Lstride, d_Uin, gamma, d_gvec, B, cs, d_active, stream, osc2);
         // ---- E = rand(rng, P, K) ----------------------------------------------------------------
         time_begin(1);
@@ -967,6 +951,24 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
         }
         if (!dsc && !fused) launch_trmm_LZ_mfma(Lp, Lstride, d_Z, d_E, B, cs, K, d_active, stream, osc2);
         time_end();
+        // (queued BEHIND the sampler / L.Z launch of this iteration: the event record that forks the side chain costs the main stream ~6-10 us, and there it
+        // sits under the L.Z kernel instead of between the Cholesky and L.Z on the critical path; the trace still has ~200 us of slack before the Lanczos kernel needs it)
+        {
+            // :cmamppi: tr(Σ^-1) (= ||L^-1||_F², times σ² when L factors σ²Σ) of THIS iteration's update needs only the factor this iteration samples from -- start it now on the free
+            // second stream (low wave priority: it shares the chip with the sampler and the rollout, which at small batches leave most CUs idle), so
+            // that the Lanczos kernel of the update never waits for it.  It used to start behind the rollout, beside the sort, and part of it stayed on
+            // the critical path: C4 6.56 -> 5.98 ms per step at one trial, 8.25 -> 7.70 at 8, 11.2 -> 10.8 at 16, neutral from 32 on
+            // (MPOPIS_TRTRI_EARLY=0 restores the old placement for A/B runs).
+            static const int env_early = [] { const char* e = getenv("MPOPIS_TRTRI_EARLY"); return e ? atoi(e) : 1; }();
+            trtri_early = false;
+            if (env_early && pol == MPOPIS_POL_CMAMPPI && side_free && n < N) {
+                (void)hipEventRecord(ev_skew[2], stream);
+                (void)hipStreamWaitEvent(xstream[0], ev_skew[2], 0);
+                launch_trtri_fro(Lp, Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
+                (void)hipEventRecord(ev_join[0], xstream[0]);
+                trtri_early = true;
+            }
+        }
         if (n == 1 && record_after_first_sampler) (void)hipEventRecord(record_after_first_sampler, stream);   // the next part starts when this one enters its first rollout
         // ---- trajectory_cost = simulate_model(pol, env, E, Σ_inv, U_orig) -------------------------
         rollout(d_Ucur, d_Uin, gamma != 0.0 ? d_gvec : nullptr, d_active, d_iters, n);   // also records iters_run = n for the active slots
