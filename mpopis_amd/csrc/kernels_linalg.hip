@@ -235,6 +235,222 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register-resident variant for 128 < n <= 304 (cs = 300: three cars), one workgroup of 8 waves per matrix.  The lower triangle of a
+// 304 x 304 matrix is 190 tiles of 16 x 16 -- 361 KB, more than a CU's LDS, but a CU's register file is 512 KB: every wave keeps up
+// to 17 tiles in the accumulator layout of v_mfma_f64_16x16x4 (lane (li, lk), element q <-> row li, column lk + 4 q) for the whole
+// factorisation, 136 of its 256 registers at two waves per SIMD, and its first seven tiles -- block columns 0 .. 3, done after the
+// fourth panel -- in a private corner of LDS (the diagonal-block routine needs ~110 registers of its own).  Nothing of the working
+// matrix ever moves between waves: per panel j only the solved panel strip (both operands of the rank-16 update, 304 x 16) goes
+// through LDS, and the 16 x 16 diagonal block through the scratch of diag16_factor.  Tile number t (column-major order of the lower
+// triangle) lives in slot t / 8 of wave t % 8, so the trailing tiles of every stage are spread evenly (+-1), a wave's active tiles
+// are always the tail of its slot list and its tiles of one block column are consecutive slots.  Per panel j:
+//   A  every wave solves its (at most three) tiles of block column j against the diagonal block, three independent chains of
+//      panel_solve_tile interleaved (the tile IS the operand), and writes them to the strip and to the output   | barrier
+//   B  the owner of diagonal block j+1 updates it and factors it at raised priority (look-ahead); every wave updates its trailing
+//      tiles from the strip in groups of four slots of straight-line code (slots that are not active read the strip's zero block):
+//      product of the two strip rows first, then subtracted -- the arithmetic of k_potrf_global in the same order, so the factor
+//      has the same bits                                                                                        | barrier
+// The barriers wait for LDS only: the output stores drain behind the arithmetic, nothing in the kernel reads them back.
+// Against k_potrf_coop at n = 300: no hand-offs between CUs (19 x ~8 us there); one CU's matrix rate is ample (4560 MFMAs).
+// ---------------------------------------------------------------------------------------------
+#ifdef POTRF_PROF
+__device__ unsigned long long g_rprof[8 * 32 * 6];
+void debug_read_rprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rprof), sizeof(g_rprof)); }
+#define RPROF(j_, k_) do { if (b == 0 && lane == 0) g_rprof[(wv * 32 + (j_)) * 6 + (k_)] = wall_clock64(); } while (0)
+#else
+#define RPROF(j_, k_) do { } while (0)
+#endif
+constexpr int kRegWaves = 8, kRegSlots = 24, kRegLdsSlots = 7, kRegMinPan = 16, kRegMaxPan = 19, kRegPS = kNB + 1;
+static_assert(kRegMaxPan * (kRegMaxPan + 1) / 2 <= kRegWaves * kRegSlots, "every tile of the lower triangle needs a slot");
+static_assert(kRegMaxPan < 32 && kRegSlots % 4 == 0, "tile key = 32 * block column + block row; update groups of four slots");
+size_t potrf_reg_lds_bytes(int n) {
+    const int npad = (n + kNB - 1) / kNB * kNB;
+    return ((size_t)npad * kRegPS + (size_t)kRegWaves * kRegLdsSlots * 256) * sizeof(double);
+}
+__global__ void __launch_bounds__(64 * kRegWaves) k_potrf_reg(const double* __restrict__ A, size_t Astride, double* __restrict__ Lout,
+                                                              int n, const double* scale, int* status, int* active) {
+    __builtin_amdgcn_s_setprio(2);
+    extern __shared__ __attribute__((aligned(16))) double smem[];              // strip[npad][17], then the LDS tile slots [wave][slot][q][lane]
+    __shared__ DiagScratch dsh;
+    __shared__ double dtile[kNB][kNB + 1];
+    __shared__ int failed;
+    const int b = blockIdx.x;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npan = (n + kNB - 1) / kNB, npad = npan * kNB;
+    const double* Ab = A + (size_t)b * Astride;
+    double* Lb = Lout + (size_t)b * n * n;
+    double* P = smem;
+    double* Tl = smem + (size_t)npad * kRegPS + (size_t)wv * kRegLdsSlots * 256 + lane;      // this lane's entries of LDS slot s: Tl[(s * 4 + q) * 64]
+    const double sc = scale ? scale[b] : 1.0;
+    if (tid == 0) failed = 0;
+    RPROF(31, 0);
+    // the strip's rows 0 .. 15 are never written (block row 0 holds only the first diagonal block): the zero block
+    for (int e = tid; e < kNB * kRegPS; e += 64 * kRegWaves) P[e] = 0.0;
+    // slot s <-> tile number 8 s + wv; key = 32 * block column + block row, -1: no tile
+    int key[kRegSlots];
+    {
+        int c = 0, pp = wv;
+#pragma unroll
+        for (int s = 0; s < kRegSlots; ++s) {
+            while (c < npan && pp >= npan - c) { pp -= npan - c; ++c; }
+            key[s] = (c < npan) ? 32 * c + c + pp : -1;
+            pp += kRegWaves;
+        }
+    }
+    v4f64_l tile[kRegSlots - kRegLdsSlots];
+    auto get = [&](int s) -> v4f64_l {                                         // s is a compile-time constant wherever this is called
+        if (s >= kRegLdsSlots) return tile[s - kRegLdsSlots];
+        v4f64_l t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = Tl[(s * 4 + q) * 64];
+        return t;
+    };
+    auto put = [&](int s, const v4f64_l& t) {
+        if (s >= kRegLdsSlots) { tile[s - kRegLdsSlots] = t; return; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Tl[(s * 4 + q) * 64] = t[q];
+    };
+#pragma unroll
+    for (int s = 0; s < kRegSlots; ++s) {                                      // tiles <- sc * A, identity beyond n (a CU pulls ~50 GB/s: 8 us at n = 300)
+        v4f64_l t = {0.0, 0.0, 0.0, 0.0};
+        if (key[s] >= 0) {
+            const int i = (key[s] & 31) * kNB + li;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = (key[s] >> 5) * kNB + lk + 4 * q;
+                const double av = Ab[(unsigned)(min(i, n - 1) + min(col, n - 1) * n)];      // 32-bit element index (n <= 304)
+                t[q] = (i < n && col < n) ? sc * av : ((i == col) ? 1.0 : 0.0);
+            }
+        }
+        put(s, t);
+    }
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };   // LDS visibility only: the output stores stay in flight
+    // the diagonal block (wave-uniform calls): through LDS into the layout of diag16_factor; factor -> output, dsh
+    auto factor_diag = [&](const v4f64_l& t) {                                 // -> dsh (L with zeros above the diagonal, the 4x4 inverses); the output copy follows in phase A
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dtile[li][lk + 4 * q] = t[q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int ln = lane;                                                         // opaque: the routine's per-lane selection weights (20 doubles) are loop
+        asm volatile("" : "+v"(ln));                                           // invariants otherwise, hoisted out of the panel loop and spilled
+        const bool bad = diag16_factor(ln, [&](int i, int c) { return dtile[i][c]; }, [&](int, int, double) {}, dsh);
+        if (bad && lane == 0) failed = 1;
+    };
+    auto update = [&](v4f64_l& t, int r, int c) {                              // t -= (strip rows of block r) x (strip rows of block c)'
+        v4f64_l acc = {0.0, 0.0, 0.0, 0.0};
+        const double* pa = P + (size_t)(r * kNB + li) * kRegPS + lk;
+        const double* pb = P + (size_t)(c * kNB + li) * kRegPS + lk;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pb[kk * 4], pa[kk * 4], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] -= acc[q];
+    };
+#define MPOPIS_REG_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23)
+    RPROF(31, 1);
+    lds_barrier();
+    RPROF(31, 2);
+    if (wv == 0) factor_diag(get(0));                                          // tile 0 = block (0, 0)
+    lds_barrier();
+    int td = 0;                                                                // tile number of diagonal block j
+    for (int j = 0; j < npan; ++j) {
+        if (failed) break;
+        const int j0 = j * kNB;
+        RPROF(j, 0);
+        // ---- A: block column j below the diagonal block: tiles td + 1 .. td + npan - 1 - j, mine = those congruent wv mod 8 ----------
+        {
+            const PanelOps o = panel_solve_operands(lane, dsh);
+            const int t1 = td + 1 + ((wv - (td + 1)) & 7), tlast = td + npan - 1 - j;
+            const int cnt = (t1 <= tlast) ? ((tlast - t1) >> 3) + 1 : 0;       // 0 .. 3
+            const int r1 = j + (t1 - td);
+            auto emit = [&](const double (&a)[4], int r) {
+                const int i = r * kNB + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = q * 4 + lk;
+                    P[(size_t)i * kRegPS + cl] = a[q];
+                    if (i < n && j0 + cl < n) Lb[(unsigned)(i + (j0 + cl) * n)] = a[q];
+                }
+            };
+            for (int done = 0; done < cnt; done += 2) {                        // two tiles at a time: two independent chains of 7 MFMAs, interleaved
+                v4f64_l x0 = {0.0, 0.0, 0.0, 0.0}, x1 = x0;                     // (an FP64 MFMA occupies the pipe for 64 cycles; a third chain costs registers)
+                switch ((t1 >> 3) + done) {
+#define MPOPIS_REG_FETCH2(S) case S: x0 = get(S); x1 = get((S) + 1 < kRegSlots ? (S) + 1 : (S)); break;
+                    MPOPIS_REG_CASES(MPOPIS_REG_FETCH2)
+#undef MPOPIS_REG_FETCH2
+                }
+                double a0[4] = {x0[0], x0[1], x0[2], x0[3]}, a1[4] = {x1[0], x1[1], x1[2], x1[3]};
+                if (cnt - done >= 2) {
+                    panel_solve_tile(o, a0); panel_solve_tile(o, a1);
+                    emit(a0, r1 + 8 * done); emit(a1, r1 + 8 * done + 8);
+                } else {
+                    panel_solve_tile(o, a0);
+                    emit(a0, r1 + 8 * done);
+                }
+            }
+            RPROF(j, 1);
+            if (wv == ((j + 4) & 7)) {                                         // the diagonal block itself (dsh.L: zeros above the diagonal included)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = lk + 4 * q;
+                    if (j0 + li < n && j0 + cl < n) Lb[(unsigned)(j0 + li + (j0 + cl) * n)] = dsh.L[li][cl];
+                }
+            }
+            // zeros above the diagonal block of these columns (rows 0 .. j0-1), two columns per wave: nobody waits for them
+            for (int cl = wv; cl < kNB; cl += kRegWaves)
+                if (j0 + cl < n) for (int i = lane; i < j0; i += 64) Lb[(unsigned)(i + (j0 + cl) * n)] = 0.0;
+        }
+        RPROF(j, 2);
+        lds_barrier();
+        RPROF(j, 3);
+        if (j + 1 == npan) break;
+        // ---- B: rank-16 update of everything to the right; the next diagonal block first, factored at once ---------------------
+        const int td1 = td + npan - j;                                          // tile number of diagonal block j + 1
+        if (wv == (td1 & 7)) {
+            v4f64_l t = {0.0, 0.0, 0.0, 0.0};
+            switch (td1 >> 3) {
+#define MPOPIS_REG_FETCH1(S) case S: t = get(S); break;
+                MPOPIS_REG_CASES(MPOPIS_REG_FETCH1)
+#undef MPOPIS_REG_FETCH1
+            }
+            update(t, j + 1, j + 1);
+            RPROF(j, 0);
+            __builtin_amdgcn_s_setprio(3);
+            factor_diag(t);
+            __builtin_amdgcn_s_setprio(2);
+        }
+        RPROF(j, 4);
+        {
+            const int s0 = (td1 - wv + 8) >> 3;                                 // first slot with tile number > td1
+            auto group = [&](int g) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = 4 * g + u;                                    // (compile-time after unrolling)
+                    const bool act = s >= s0 && key[s] >= 0;
+                    const int k = act ? key[s] : 0;                             // inactive: block (0, 0) of the strip = zeros, the tile keeps its bits
+                    v4f64_l t = get(s); update(t, k & 31, k >> 5); put(s, t);
+                }
+            };
+            switch (s0 >> 2) {
+                case 0: group(0); [[fallthrough]];
+                case 1: group(1); [[fallthrough]];
+                case 2: group(2); [[fallthrough]];
+                case 3: group(3); [[fallthrough]];
+                case 4: group(4); [[fallthrough]];
+                case 5: group(5);
+            }
+        }
+        RPROF(j, 5);
+        lds_barrier();
+        td = td1;
+    }
+#undef MPOPIS_REG_CASES
+    if (failed && tid == 0) { if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Cooperative variant for matrices that do not fit one CU's LDS (cs = 300): G workgroups ("cluster") per matrix.  A single CU
 // moves ~57 GB/s from L2 and has 1/256 of the chip's FP64 matrix rate -- k_potrf_global spends most of its 234 us on the
 // trailing read-modify-write.  Here the 16-wide block columns (panels) are dealt round-robin to the G workgroups and live in
@@ -483,6 +699,16 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
         static std::atomic<unsigned long long> seen{0};
         ensure_dyn_lds((const void*)k_potrf_lds, 150 * 1024, seen);
         hipLaunchKernelGGL(k_potrf_lds, dim3(B), dim3(512), bytes, s, A, Astride, L, n, npad, scale, status, active, n <= kPanelRows ? panel : nullptr, pstride);
+        return;
+    }
+    static const int env_reg = [] { const char* e = getenv("MPOPIS_POTRF_REG"); return e ? atoi(e) : 1; }();      // tests / A-B: 0 = the cluster and global kernels only
+    // n = 241 .. 304: the register-resident kernel (n = 300: 133 us at one slot, 140 us at 64 -- clusters 160, one-workgroup global 225; below 16 panels
+    // its fixed costs -- 8 us of loads through one CU, ~5 us per panel whatever its height -- lose to the clusters: n = 240: 123 vs 120, n = 144: 84 vs 68)
+    if (env_reg && npan >= kRegMinPan && npan <= kRegMaxPan) {
+        static std::atomic<unsigned long long> seenr{0};
+        const size_t rbytes = potrf_reg_lds_bytes(n);
+        ensure_dyn_lds((const void*)k_potrf_reg, (int)potrf_reg_lds_bytes(kRegMaxPan * kNB), seenr);
+        hipLaunchKernelGGL(k_potrf_reg, dim3(B), dim3(64 * kRegWaves), rbytes, s, A, Astride, L, n, scale, status, active);
         return;
     }
     static const int env_G = [] { const char* e = getenv("MPOPIS_POTRF_G"); return e ? atoi(e) : -1; }();

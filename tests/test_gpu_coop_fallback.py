@@ -28,7 +28,7 @@ def test_harness_clusters_that_lose_a_partner_are_redone():
     build.build()
     subprocess.run(["bash", os.path.join(ROOT, "tools", "build_kbench_linalg.sh")], capture_output=True, text=True, timeout=600)
     exe = os.path.join(ROOT, "tools", "kbench_linalg_bin")
-    env = dict(os.environ, MPOPIS_COOP_TEST_DROP="1", MPOPIS_COOP_WAIT_US="2000")
+    env = dict(os.environ, MPOPIS_COOP_TEST_DROP="1", MPOPIS_COOP_WAIT_US="2000", MPOPIS_POTRF_REG="0")    # (n = 300 would take the one-workgroup register kernel)
     r = subprocess.run([exe, "4", "300"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     t = r.stdout
@@ -50,6 +50,12 @@ def test_engine_steps_survive_lost_partners():
     assert np.max(np.abs(np.array(got["control"]) - np.array(ref["control"]))) < 1e-8      # cluster vs one-workgroup kernels: rounding only
     none = _run_case([3, 512, 3], {"MPOPIS_NO_COOP": "1"})
     assert np.max(np.abs(np.array(none["control"]) - np.array(ref["control"]))) < 1e-8
+    # the Cholesky clusters too (cs = 300 takes the register-resident kernel by default; the clusters serve n > 304 and n <= 240)
+    ref2 = _run_case([3, 512, 3], {"MPOPIS_POTRF_REG": "0"})
+    got2 = _run_case([3, 512, 3], {"MPOPIS_POTRF_REG": "0", "MPOPIS_COOP_TEST_DROP": "1", "MPOPIS_COOP_WAIT_US": "2000"})
+    assert got2["iters"] == ref2["iters"] == ref["iters"]
+    assert np.array_equal(np.array(ref2["control"]), np.array(ref["control"]))               # the register kernel has the clusters' bits
+    assert np.max(np.abs(np.array(got2["control"]) - np.array(ref["control"]))) < 1e-8
 
 
 def test_closed_loop_survives_lost_partners_and_stops_using_clusters():

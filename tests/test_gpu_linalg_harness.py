@@ -1,4 +1,4 @@
-"""The dense linear algebra kernels (Cholesky: LDS / cooperative / one-workgroup global; triangular-inverse trace; Lanczos inverse square root:
+"""The dense linear algebra kernels (Cholesky: LDS / register-resident / cooperative / one-workgroup global; triangular-inverse trace; Lanczos inverse square root:
 one workgroup / cooperative) exercised directly, below the policy level, through the C++ harness tools/kbench_linalg.hip: sizes on both sides of
 every kernel-selection threshold, batches that do and do not allow co-resident clusters."""
 import os, re, shutil, subprocess
@@ -30,7 +30,32 @@ def _num(pattern, text):
                                  (3, 129), (2, 145), (4, 200), (8, 300), (2, 333), (2, 384),   # k_potrf_coop, cooperative Lanczos from n = 160
                                  (24, 300), (48, 300), (2, 400)])                             # 48 x 6 > CUs and n = 400 (LDS too small for clusters): k_potrf_global
 def test_linalg_kernels(harness, B, n):
-    r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=120)
+    _check(harness, B, n, {})
+
+
+@pytest.mark.parametrize("B,n", [(8, 300), (2, 256), (2, 304), (48, 300)])
+def test_linalg_kernels_without_the_register_cholesky(harness, B, n):
+    """n = 241 .. 304 goes to k_potrf_reg by default; the cluster / one-workgroup kernels stay behind it for n > 304 and as its reference"""
+    _check(harness, B, n, {"MPOPIS_POTRF_REG": "0"})
+
+
+@pytest.mark.parametrize("B,n", [(1, 300), (64, 300), (3, 250), (2, 272), (2, 304), (5, 241)])
+def test_register_cholesky_has_the_bits_of_the_other_kernels(harness, B, n):
+    """k_potrf_reg keeps the arithmetic of k_potrf_global / k_potrf_coop (same diagonal-block routine, same panel solve, product of the strip rows
+    first and then the subtraction): the factors are bit-identical, zeros above the diagonal included (the harness poisons the output first)"""
+    hashes = []
+    for env in ({}, {"MPOPIS_POTRF_REG": "0"}, {"MPOPIS_POTRF_REG": "0", "MPOPIS_POTRF_G": "0"}):
+        r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=120, env=dict(os.environ, KB_POTRF_ONLY="1", **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert _num(r"potrf status min (-?\d+)", r.stdout) == 0 and _num(r"max \|upper\| = ([0-9.e+-]+)", r.stdout) == 0.0
+        m = re.search(r"potrf L hash ([0-9a-f]+)", r.stdout)
+        assert m, r.stdout
+        hashes.append(m.group(1))
+    assert hashes[0] == hashes[1] == hashes[2], hashes
+
+
+def _check(harness, B, n, env):
+    r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout + r.stderr
     t = r.stdout
     assert _num(r"potrf status min (-?\d+)", t) == 0

@@ -5,6 +5,7 @@
 #include <vector>
 #include <random>
 #include <cmath>
+#include <cstring>
 using namespace mpopis;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 template <class F> float timeit(F f, int reps, hipStream_t s) {
@@ -17,7 +18,7 @@ template <class F> float timeit(F f, int reps, hipStream_t s) {
     return ms / reps * 1e3f;
 }
 #ifdef POTRF_PROF
-namespace mpopis { void debug_read_prof(unsigned long long* out); void debug_read_lprof(unsigned long long* out); }
+namespace mpopis { void debug_read_rprof(unsigned long long* out); void debug_read_prof(unsigned long long* out); void debug_read_lprof(unsigned long long* out); }
 #endif
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8, n = argc > 2 ? atoi(argv[2]) : 300;
@@ -50,9 +51,18 @@ int main(int argc, char** argv) {
     CoopCtx pc; pc.flags = dflags; pc.epoch = &epoch; pc.redo = dredo; pc.timeouts = dredo + 2 * B;
     CoopCtx lc; lc.flags = dlx; lc.epoch = &lep; lc.redo = dredo + B; lc.timeouts = dredo + 2 * B;
     if (getenv("KB_NO_COOP")) { pc = CoopCtx(); lc = CoopCtx(); }
+    CK(hipMemset(dL, 0xff, nn * B * 8));                 // poison: the kernels must write the zeros above the diagonal themselves
     printf("potrf                 %8.1f us\n", timeit([&] { launch_potrf(dA, nn, dL, B, n, nullptr, dstatus, dact, s, pc); }, 20, s));
 #ifdef POTRF_PROF
-    {
+    if (getenv("KB_RPROF")) {
+        std::vector<unsigned long long> pr(8 * 32 * 6); mpopis::debug_read_rprof(pr.data());
+        const int npan = (n + 15) / 16;
+        unsigned long long t00 = ~0ull; for (auto v : pr) if (v && v < t00) t00 = v;
+        printf("   register Cholesky, per stage j and wave: start solved zeros barrierX diag updates  [us, 100 MHz clock]\n");
+        for (int w = 0; w < 8; ++w) { const unsigned long long* q = &pr[(w * 32 + 31) * 6]; printf("   load w=%d: start %7.2f loads-consumed %7.2f barrier %7.2f\n", w, (q[0]-t00)*0.01, (q[1]-t00)*0.01, (q[2]-t00)*0.01); }
+        for (int j = 0; j < npan; ++j) for (int w = 0; w < 8; ++w) { const unsigned long long* q = &pr[(w * 32 + j) * 6];
+            printf("   j=%2d w=%d: %7.2f %7.2f %7.2f %7.2f %7.2f %7.2f\n", j, w, (q[0]-t00)*0.01, (q[1]-t00)*0.01, (q[2]-t00)*0.01, (q[3]-t00)*0.01, q[4] ? (q[4]-t00)*0.01 : 0.0, q[5] ? (q[5]-t00)*0.01 : 0.0); }
+    } else {
         std::vector<unsigned long long> pr(8 * 32 * 6); mpopis::debug_read_prof(pr.data());
         const int G = getenv("MPOPIS_POTRF_G") ? atoi(getenv("MPOPIS_POTRF_G")) : 6, npan = (n + 15) / 16;
         unsigned long long t00 = ~0ull; for (auto v : pr) if (v && v < t00) t00 = v;
@@ -71,7 +81,11 @@ int main(int argc, char** argv) {
             for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) up = fmax(up, fabs(L[i + (size_t)j * n]));
         }
         printf("   potrf max |LL'-A| = %.3e, max |upper| = %.1e\n", err, up);
+        unsigned long long h = 1469598103934665603ull;
+        for (size_t e = 0; e < Lall.size(); ++e) { unsigned long long w; memcpy(&w, &Lall[e], 8); h = (h ^ w) * 1099511628211ull; }
+        printf("   potrf L hash %016llx\n", h);
     }
+    if (getenv("KB_POTRF_ONLY")) return 0;
     double* ddinv; CK(hipMalloc(&ddinv, trtri_dinv_doubles(B, n) * 8));
     printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv); }, 20, s));
     if (getenv("KB_LANCZOS_ONCE")) {
