@@ -175,7 +175,9 @@ __global__ void __launch_bounds__(1024) k_potrf_global(const double* __restrict_
     __threadfence_block();
     __syncthreads();
     auto factor_diag_inv = [&](int j0) {
-        const bool bad = diag16_factor(lane,
+        int ln = lane;                                   // opaque (see k_potrf_reg): keeps the routine's 20 selection weights out of the panel loop's live set
+        asm volatile("" : "+v"(ln));
+        const bool bad = diag16_factor(ln,
             [&](int i, int c) { return (j0 + i < m && j0 + c < m) ? W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] : ((i == c) ? 1.0 : 0.0); },
             [&](int i, int c, double v) { if (j0 + i < m && j0 + c < m) W[(size_t)(j0 + i) + (size_t)(j0 + c) * ldw] = v; }, dsh);
         if (bad && lane == 0) failed = 1;
@@ -398,9 +400,10 @@ __global__ void __launch_bounds__(64 * kRegWaves) k_potrf_reg(const double* __re
                     if (j0 + li < n && j0 + cl < n) Lb[(unsigned)(j0 + li + (j0 + cl) * n)] = dsh.L[li][cl];
                 }
             }
-            // zeros above the diagonal block of these columns (rows 0 .. j0-1), two columns per wave: nobody waits for them
-            for (int cl = wv; cl < kNB; cl += kRegWaves)
-                if (j0 + cl < n) for (int i = lane; i < j0; i += 64) Lb[(unsigned)(i + (j0 + cl) * n)] = 0.0;
+            // the zeros above this panel's diagonal block: in phase B, by the waves that wait for the factoring one there -- except behind the last panel
+            if (j + 1 == npan)
+                for (int cl = wv; cl < kNB; cl += kRegWaves)
+                    if (j0 + cl < n) for (int i = lane; i < j0; i += 64) Lb[(unsigned)(i + (j0 + cl) * n)] = 0.0;
         }
         RPROF(j, 2);
         lds_barrier();
@@ -443,6 +446,10 @@ __global__ void __launch_bounds__(64 * kRegWaves) k_potrf_reg(const double* __re
             }
         }
         RPROF(j, 5);
+        if (wv != (td1 & 7) && j0 > 0) {                                        // zeros above the diagonal block of columns j0 .. j0+15 (rows 0 .. j0-1): seven waves share
+            for (int cl = (wv - (td1 & 7) - 1) & 7; cl < kNB; cl += kRegWaves - 1)      // the 16 columns while the eighth factors -- nobody waits for these stores
+                for (int i = lane; i < j0; i += 64) Lb[(unsigned)(i + (j0 + cl) * n)] = 0.0;
+        }
         lds_barrier();
         td = td1;
     }
@@ -559,7 +566,9 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
             if (tid == 0) __hip_atomic_store(&fl[pending], ok_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (wv == 0) {
-            const bool bad = diag16_factor(lane, [&](int i, int cc) { return W[i + cc * ld]; }, [&](int i, int cc, double v) { W[i + cc * ld] = v; }, dsh);
+            int ln = lane;                              // opaque (see k_potrf_reg)
+            asm volatile("" : "+v"(ln));
+            const bool bad = diag16_factor(ln, [&](int i, int cc) { return W[i + cc * ld]; }, [&](int i, int cc, double v) { W[i + cc * ld] = v; }, dsh);
             if (bad && lane == 0) sh_fail = 1;
         }
         __syncthreads();
