@@ -224,8 +224,10 @@ size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot = 1);
 int invsqrt_coop_groups(int B, int n, int share = 1);      // workgroups per matrix the cooperative Lanczos would use for this batch (1: not cooperative)
 int invsqrt_max_n();
 size_t trtri_dinv_doubles(int B, int n);      // workspace: the inverses of the diagonal 16 x 16 blocks, [B][ceil(n/16)][256]
-void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio = true);
-void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
+size_t lanczos_prep_doubles(int B);           // workspace: per slot fro, spectrum bounds, 64 quadrature nodes (left by launch_trtri_fro for launch_lanczos_invsqrt)
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio = true,
+                      const double* A = nullptr, const double* scale = nullptr, double* prep = nullptr, unsigned long long* sync2 = nullptr);
+void launch_lanczos_invsqrt(const double* A, const double* prep, const double* bvec, size_t bstride,
                             double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
                             int regions_per_slot = 1, const CoopCtx& coop = CoopCtx());
 size_t invsqrt_coop_words(int B, int n);

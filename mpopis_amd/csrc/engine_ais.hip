@@ -123,7 +123,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
             (void)hipStreamWaitEvent(xstream[0], ev_fork, 0);
             // (no `active` predicate on the side stream: launch_sortperm below clears active[b] for the early break concurrently; an
             // inactive slot's trace is never consumed, so computing it is merely wasted, deterministic work)
-            launch_trtri_fro(cur_L, cur_Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv);
+            launch_trtri_fro(cur_L, cur_Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, true, d_Sig, cur_L_scaled ? d_sig2 : nullptr, d_lan_prep, d_tri_cnt);
             (void)hipEventRecord(ev_join[0], xstream[0]);
         }
         static const int env_small = [] { const char* e = getenv("MPOPIS_CE_SMALL"); return e ? atoi(e) : 1; }();      // 0: always the general path; 2: small kernel, sort in its own launch (A/B, tests)
@@ -166,8 +166,8 @@ int mpopis_handle::ais_update(int n, bool injected) {
         // C = Σ^-0.5 (:580) is only consumed as C*δw (:581) and ||C||_F (:593): neither needs the matrix.  cur_L = chol(Σ) or chol(σ²Σ) is the
         // factor this iteration sampled from (same Σ: the update :598 comes after), so tr(Σ^-1) = ||L^-1||_F² or σ² ||L^-1||_F²
         if (side) (void)hipStreamWaitEvent(stream, ev_join[0], 0);
-        else launch_trtri_fro(cur_L, cur_Lstride, d_fro_part, B, cs, d_active, stream, d_tri_dinv);
-        launch_lanczos_invsqrt(d_Sig, cur_L_scaled ? d_sig2 : nullptr, dw, (size_t)3 * cs, d_fro_part, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream,
+        else launch_trtri_fro(cur_L, cur_Lstride, d_fro_part, B, cs, d_active, stream, d_tri_dinv, true, d_Sig, cur_L_scaled ? d_sig2 : nullptr, d_lan_prep, d_tri_cnt);
+        launch_lanczos_invsqrt(d_Sig, d_lan_prep, dw, (size_t)3 * cs, d_lanV, d_Cdw, d_fro, d_lan_m, B, cs, d_status, d_active, stream,
                                lan_regions, lan_coop());
         launch_cma_paths(d_Cdw, d_fro, d_E, d_order, d_cma_ws, d_Ucur, d_cma_scal, d_cma_vec, d_sig2, B, cs, K, n, cma_consts, m_elite, d_active, stream);
         launch_cma_sigma_update(d_Sig, d_cma_scal, d_cma_vec, B, cs, cma_consts, m_elite, d_active, stream);

@@ -253,7 +253,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
         rc |= dalloc(h, &h->d_cma_ws, (size_t)K);
         h->lan_regions = invsqrt_coop_groups(B, cs);
         rc |= dalloc(h, &h->d_lanV, invsqrt_workspace_doubles(B, cs, h->lan_regions)); rc |= dalloc(h, &h->d_lan_x, invsqrt_coop_words(B, cs)); rc |= dalloc(h, &h->d_Cdw, (size_t)B * cs);
-        rc |= dalloc(h, &h->d_fro_part, (size_t)B * ((cs + 15) / 16)); rc |= dalloc(h, &h->d_tri_dinv, trtri_dinv_doubles(B, cs)); rc |= dalloc(h, &h->d_fro, B); rc |= dalloc(h, &h->d_lan_m, B);
+        rc |= dalloc(h, &h->d_fro_part, (size_t)B * ((cs + 15) / 16)); rc |= dalloc(h, &h->d_tri_dinv, trtri_dinv_doubles(B, cs)); rc |= dalloc(h, &h->d_fro, B); rc |= dalloc(h, &h->d_lan_m, B); rc |= dalloc(h, &h->d_lan_prep, lanczos_prep_doubles(B)); rc |= dalloc(h, &h->d_tri_cnt, 2 * (size_t)B);
     }
     if (cfg->log_trajectories) rc |= dalloc(h, &h->d_traj, (size_t)B * K * h->T * h->ss);
     if (rc) { g_create_error = h->err; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
@@ -777,7 +777,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_resu, K); mv(d_accept, K); mv(d_alias_need, 1); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
     mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
-    mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs, lan_regions)); mv(d_lan_x, (ptrdiff_t)invsqrt_coop_words(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_tri_dinv, (ptrdiff_t)trtri_dinv_doubles(1, cs)); mv(d_fro, 1); mv(d_lan_m, 1);
+    mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs, lan_regions)); mv(d_lan_x, (ptrdiff_t)invsqrt_coop_words(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_tri_dinv, (ptrdiff_t)trtri_dinv_doubles(1, cs)); mv(d_fro, 1); mv(d_lan_m, 1); mv(d_lan_prep, (ptrdiff_t)lanczos_prep_doubles(1)); mv(d_tri_cnt, 2);
     mv(d_coop_flags, (ptrdiff_t)potrf_coop_flag_words(1, cs)); mv(d_potrf_redo, 1); mv(d_lan_redo, 1);
     mv(alive_gate, 1);
 }
@@ -964,7 +964,7 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
             if (env_early && pol == MPOPIS_POL_CMAMPPI && side_free && n < N) {
                 (void)hipEventRecord(ev_skew[2], stream);
                 (void)hipStreamWaitEvent(xstream[0], ev_skew[2], 0);
-                launch_trtri_fro(Lp, Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false);
+                launch_trtri_fro(Lp, Lstride, d_fro_part, B, cs, nullptr, xstream[0], d_tri_dinv, false, d_Sig, cur_L_scaled ? d_sig2 : nullptr, d_lan_prep, d_tri_cnt);   // + the Lanczos run's spectrum bounds / quadrature nodes (Σ and σ² do not change before the update consumes them)
                 (void)hipEventRecord(ev_join[0], xstream[0]);
                 trtri_early = true;
             }

@@ -53,7 +53,7 @@ struct mpopis_handle {
     std::vector<double> cma_ws_host;
     double *d_cma_scal = nullptr, *d_cma_vec = nullptr, *d_sig2 = nullptr, *d_cma_ws = nullptr;
     double* d_tri_dinv = nullptr;                                                          // [B][ceil(cs/16)][256] diagonal-block inverses of L (k_trtri_diag)
-    double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
+    double *d_lanV = nullptr, *d_Cdw = nullptr, *d_fro_part = nullptr, *d_fro = nullptr, *d_lan_prep = nullptr;   // Σ^-½ δw and tr(Σ^-1) (kernels_invsqrt.hip)
     unsigned long long* d_coop_flags = nullptr; unsigned long long coop_epoch = 0;         // cooperative Cholesky (cs > 128): panel flags [B][ceil(cs/16)], launch counter
     unsigned long long* d_lan_x = nullptr; int lan_regions = 1;                            // cooperative Lanczos: exchange granules, basis spill regions per slot
     int *d_potrf_redo = nullptr, *d_lan_redo = nullptr, *d_coop_timeouts = nullptr;         // cooperative kernels that gave up (CoopCtx, engine.h)
@@ -63,6 +63,7 @@ struct mpopis_handle {
     mpopis::CoopCtx lan_coop() { mpopis::CoopCtx c; if (!coop_disabled) { c.flags = d_lan_x; c.epoch = &coop_epoch; c.redo = d_lan_redo; c.timeouts = d_coop_timeouts; c.share = coop_share; } return c; }
     int* d_alias_need = nullptr;                                                           // :pmcmppi: slots whose alias table the parallel construction could not certify
     int* d_lan_m = nullptr;                                                                // Lanczos steps taken per slot (diagnostic)
+    unsigned long long* d_tri_cnt = nullptr;                                               // [B][2]: arrival counter of a slot's trace workgroups (the last one prepares the Lanczos run) and their ||Σ||_inf; zero between launches
     double *d_qdist = nullptr, *d_qbeta = nullptr; int* d_qwithin = nullptr;
     // Level-3 harness
     double* d_hs = nullptr; int* d_alive = nullptr; const int* alive_gate = nullptr; bool status_sticky = false;

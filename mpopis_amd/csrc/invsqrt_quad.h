@@ -24,10 +24,12 @@ namespace mpopis {
 constexpr int kQuadAgmMax = 16;
 
 // node `j` of `N` for the interval [m, M]; returns false when m/M is outside what the AGM resolves in double precision
-MPQ_HD bool invsqrt_quad_node(double m, double M, int j, int N, double* shift, double* weight) {
+// a, c: scratch for the AGM sequence (kQuadAgmMax + 1 doubles each; the values are the same for every node).  On the device the caller passes LDS: a
+// dynamically indexed private array lives in scratch MEMORY, and the two recurrences then pay a memory round trip per level (k_lanczos_prep: 89 us
+// beside a busy chip, with these arrays in LDS a quarter of that)
+MPQ_HD bool invsqrt_quad_node(double m, double M, int j, int N, double* shift, double* weight, double* a, double* c) {
     const double k2 = m / M;
     if (!(k2 > 1e-14) || !(k2 <= 0.75)) return false;         // callers clamp m <= M/2 (a smaller lower bound stays valid)
-    double a[kQuadAgmMax + 1], c[kQuadAgmMax + 1];
     const double mpar = 1.0 - k2;
     a[0] = 1.0; c[0] = sqrt(mpar);
     double b = sqrt(k2);
@@ -47,6 +49,10 @@ MPQ_HD bool invsqrt_quad_node(double m, double M, int j, int N, double* shift, d
     *shift = m * (sn * sn) * icn2;
     *weight = (2.0 * Kp * sqrt(m) / (3.14159265358979323846 * N)) * dn * icn2;
     return true;
+}
+MPQ_HD bool invsqrt_quad_node(double m, double M, int j, int N, double* shift, double* weight) {
+    double a[kQuadAgmMax + 1], c[kQuadAgmMax + 1];
+    return invsqrt_quad_node(m, M, j, N, shift, weight, a, c);
 }
 
 }  // namespace mpopis

@@ -90,6 +90,60 @@ __global__ void __launch_bounds__(64) k_trtri_diag(const double* __restrict__ La
     for (int q = 0; q < 4; ++q) o[lane + 64 * q] = Di[lane + 64 * q];
 }
 
+// What a Lanczos run (k_lanczos_invsqrt below) needs besides A and b depends on A and L alone: fro = scale * sum_J part[J] (= tr(A^-1)), the spectrum bounds
+// M = ||A||_inf >= λ_max and m = min(1 / fro, M / 2) <= λ_min, and the 64 quadrature nodes for [m, M] (invsqrt_quad.h: an AGM / Landen recurrence with a
+// sine and an arcsine per level, ~12 us on one wave).  Until round 5 every Lanczos launch computed them itself at its first step -- 17 us on the chain
+// rollout -> sort -> δw -> Σ^-0.5 δw -> paths -> Σ' -> Cholesky -> sampler.  Now the LAST workgroup of a slot's k_trtri_fro_pair launch to finish does it (no
+// extra launch: beside a rollout that fills every SIMD's registers a new workgroup waits ~200 us for a place), i.e. on the second stream beside the rollout
+// wherever the engine runs the trace there.      prep[b] = { fro, M, m, usable (1 / 0), shift[64], weight[64] }
+constexpr int kLanPrep = 4 + 2 * 64;         // doubles per slot
+// this workgroup's share of the column abs sums of A (columns c_lo .. c_hi-1): lane-strided partial sums, then the wave butterfly -- the order the
+// Lanczos kernels themselves used.  Four columns x five row chunks of loads in flight per wave (more would cost the trace kernel its third workgroup per CU).
+__device__ __forceinline__ double lanczos_colmax(const double* __restrict__ A, int n, int c_lo, int c_hi, int tid, int nthreads) {
+    const int lane = tid & 63, wv = tid >> 6, nw = nthreads >> 6;
+    double colmax = 0.0;
+    for (int c0 = c_lo + wv; c0 < c_hi; c0 += 4 * nw) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r0 = 0; r0 < n; r0 += 320) {
+            double x[4][5];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* col = A + (size_t)min(c0 + nw * u, n - 1) * n;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) x[u][q] = col[min(r0 + lane + 64 * q, n - 1)];
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                if (r0 + lane + 64 * q < n) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] += fabs(x[u][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double t = wave_sum(a[u]); if (c0 + nw * u < c_hi) colmax = fmax(colmax, t); }
+    }
+    return colmax;
+}
+// the rest, by ONE wave: fro, the bounds, this lane's node
+__device__ __forceinline__ void lanczos_prep_slot(double Mhi, const double* part, int nb, double scale, double* __restrict__ o, int lane, double* agm_a, double* agm_c) {
+    double fro = 0.0;
+    for (int J0 = 0; J0 < nb; J0 += 8) {                        // same summation order as a plain loop, but eight loads in flight (agent scope: other workgroups wrote them)
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            t[u] = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&part[min(J0 + u, nb - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (J0 + u < nb) fro += t[u];
+    }
+    fro *= scale;
+    const double mlo = fmin(1.0 / fro, 0.5 * Mhi);
+    double sh = 0.0, wt = 0.0;
+    const bool ok = invsqrt_quad_node(mlo, Mhi, lane, 64, &sh, &wt, agm_a, agm_c);      // uniform: depends on mlo / Mhi only (false also for NaN bounds); AGM sequence in LDS
+    if (lane == 0) { o[0] = fro; o[1] = Mhi; o[2] = mlo; o[3] = ok ? 1.0 : 0.0; }
+    o[4 + lane] = sh; o[4 + 64 + lane] = wt;
+}
+
 typedef double v4f64_t __attribute__((ext_vector_type(4)));
 
 // Block products on the matrix cores.  __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc) with av = A[li][4kk + lk], bv = Bm[li][4kk + lk]
@@ -98,12 +152,18 @@ typedef double v4f64_t __attribute__((ext_vector_type(4)));
 // and block instead of 16), Bm' = X(K) from LDS (row-major: Bm[j][k] = X[k][j] is the read Xs[(4kk + lk) 16 + li]).
 template <int W>
 __global__ void __launch_bounds__(128 * W) k_trtri_fro_pair(const double* __restrict__ Lall, size_t Lstride, int n, int nb, const double* __restrict__ dinv,
-                                                            double* __restrict__ part, const int* active, int hiprio) {
+                                                            double* __restrict__ part, const int* active, int hiprio,
+                                                            const double* __restrict__ Aall, const double* __restrict__ scale, double* __restrict__ prep, unsigned long long* __restrict__ sync2) {
     if (hiprio) MPOPIS_HI_PRIO();
     const int b = blockIdx.y;
     if (active && !active[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh_tri[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = wv / W, wq = wv % W, gt = tid - grp * W * 64;   // group, wave within group, thread within group
+    double my_colmax = 0.0;
+    if (prep) {                                                               // this workgroup's columns of ||A||_inf (independent of L: the loads run under the start-up below)
+        const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+        my_colmax = lanczos_colmax(Aall + (size_t)b * n * n, n, (int)blockIdx.x * per, min(n, ((int)blockIdx.x + 1) * per), tid, 128 * W);
+    }
     const int JA = blockIdx.x, JB = nb - 1 - JA;
     const bool haveB = JB > JA;
     const int J = grp == 0 ? JA : JB, nbj = nb - J;
@@ -177,7 +237,34 @@ __global__ void __launch_bounds__(128 * W) k_trtri_fro_pair(const double* __rest
     s = wave_sum(s);
     if (lane == 0) red[wv] = s;
     __syncthreads();
-    if (live && gt == 0) { double t = 0.0; for (int w = 0; w < W; ++w) t += red[grp * W + w]; part[(size_t)b * nb + J] = t; }
+    if (live && gt == 0) {
+        double t = 0.0;
+        for (int w = 0; w < W; ++w) t += red[grp * W + w];
+        // (agent scope: written through, so that another workgroup's agent-scope load sees it -- the L2s of the eight XCDs are not coherent for plain stores)
+        __hip_atomic_store((unsigned long long*)&part[(size_t)b * nb + J], (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!prep) return;
+    // ||A||_inf: every workgroup's share into the slot's maximum (bit patterns of non-negative doubles order like the numbers; a NaN sum wins and makes the
+    // bounds unusable, as it should).  The slot's last workgroup to arrive prepares the Lanczos run and zeroes both words for the next launch.
+    __shared__ int sh_last;
+    __shared__ double agm_a[kQuadAgmMax + 1], agm_c[kQuadAgmMax + 1];
+    unsigned long long* sy = sync2 + 2 * (size_t)b;
+    {
+        unsigned long long kbits = (unsigned long long)__double_as_longlong(my_colmax);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(kbits, o, 64); kbits = (t > kbits) ? t : kbits; }
+        if (lane == 0) atomicMax(&sy[1], kbits);
+    }
+    // this workgroup's part[] entries and its maximum have arrived (vmcnt: write-through stores and atomics are acknowledged by memory) before its ticket is
+    // drawn -- no device-scope fence: on this part a release at agent scope writes the whole L2 back (tens of us once the rollouts' E lines are dirty in it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sh_last = (atomicAdd(&sy[0], 1ull) == (unsigned long long)gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!sh_last || wv != 0) return;
+    const double Mhi = __longlong_as_double((long long)__hip_atomic_load(&sy[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (lane == 0) { __hip_atomic_store(&sy[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&sy[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    lanczos_prep_slot(Mhi, part + (size_t)b * nb, nb, scale ? scale[b] : 1.0, prep + (size_t)b * kLanPrep, lane, agm_a, agm_c);
 }
 
 // Lanczos runs until the error bound is met, at most n steps (with full re-orthogonalisation the Krylov space is then
@@ -198,7 +285,7 @@ constexpr int kLanNQ = 5;                    // rows per lane and pass of the ma
 constexpr int kLanCG = 4;                    // columns whose loads are in flight together
 constexpr int kLanPivLds = 16;               // pivot rows of the final back substitution kept in LDS (longer runs: global workspace)
 constexpr double kLanTol = 1e-13;
-constexpr int kLanRed = kLanWaves + 4 + 16;  // block-reduction scratch + (COOP) the workgroups' column maxima
+constexpr int kLanRed = kLanWaves + 4 + 16;  // block-reduction scratch (+ spare)
 
 // y[b] = A[b]^-1/2 bvec[b];  fro[b] = scale[b] * sum_J part[b][J]  (= tr(A^-1) = ||A^-1/2||_F^2)
 // status: MPOPIS_ERR_NUMERIC when the spectrum bounds are unusable (non-finite input, M/m beyond 1e14)
@@ -213,13 +300,15 @@ constexpr int kLanRed = kLanWaves + 4 + 16;  // block-reduction scratch + (COOP)
 #ifdef LAN_PROF
 __device__ unsigned long long g_lprof[64 * 8];
 void debug_read_lprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lprof), sizeof(g_lprof)); }
-#define LPROF(j_, k_) do { if (blockIdx.x == 0 && tid == 0 && (j_) < 64) g_lprof[(j_) * 8 + (k_)] = wall_clock64(); } while (0)
+#define LPROF(j_, k_) do { if (blockIdx.x == 0 && tid == 0 && (j_) < 48) g_lprof[(j_) * 8 + (k_)] = wall_clock64(); } while (0)
+#define LPROFG(k_) do { if (b == 0 && threadIdx.x == 0 && g < 8) g_lprof[(48 + g) * 8 + (k_)] = wall_clock64(); } while (0)      // start-up of every workgroup of slot 0
 #else
 #define LPROF(j_, k_) do { } while (0)
+#define LPROFG(k_) do { } while (0)
 #endif
 template <bool COOP>
 __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
-                                                                 const double* __restrict__ part, int nb, const double* __restrict__ scale,
+                                                                 const double* __restrict__ prep,
                                                                  double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
                                                                  int* __restrict__ msteps, int n, int nvl, int* status, const int* active,
                                                                  int G, int Gs, unsigned long long* xbuf, unsigned long long epoch, int* redo, int* timeouts,
@@ -232,6 +321,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         if (threadIdx.x == 0) redo[b] = 0;
     }
     if (active && !active[b]) return;
+    LPROFG(0);
     if (COOP && test_drop && g == G - 1) return;                // test hook: a partner that never runs
     extern __shared__ __attribute__((aligned(16))) double sh_lan[];
     const int nc = COOP ? (n + G - 1) / G : 0, c_lo = g * nc, c_hi = min(n, c_lo + nc);       // own columns (COOP)
@@ -245,7 +335,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     double* red = cvec + n;                             // [kLanRed]
     double* pivl = red + kLanRed;                 // [2][kLanPivLds][64]  d_i and e_i = β_i/d_i of the back substitution
     double* Vl = pivl + 2 * kLanPivLds * 64;            // [nvl][n]  Lanczos basis, LDS-resident part
-    __shared__ int sh_flag;
+    __shared__ double red2[2][kLanWaves];
     const double* A = Aall + (size_t)b * n * n;
     const double* bv = bvec + (size_t)b * bstride;
     double* Vg = Vall + ((size_t)b * Gs + g) * (size_t)(n + 1 + 128) * n;  // basis vectors v_0 .. v_n (only k >= nvl are ever touched); Gs regions per slot
@@ -265,6 +355,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             for (int u = 0; u < 8; ++u) if (e0 + u * kLanThreads < cnt) part_v[e0 + u * kLanThreads] = av[u];
         }
     }
+    LPROFG(1);
     auto block_sum = [&](double v) -> double {
         v = wave_sum(v);
         __syncthreads();
@@ -275,15 +366,12 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         for (int w = 0; w < kLanWaves; ++w) t += red[w];
         return t;
     };
-    double fro = 0.0;
-    for (int J0 = 0; J0 < nb; J0 += 8) {                        // same summation order as a plain loop, but eight loads in flight (a plain loop waits
-        double t[8];                                            // for every load before the next addition: nb dependent L2 round trips)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = part[(size_t)b * nb + min(J0 + u, nb - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (J0 + u < nb) fro += t[u];
-    }
-    fro *= scale ? scale[b] : 1.0;
+    // spectrum bounds and this lane's quadrature node: k_lanczos_prep, queued behind the trace of L^-1 (off the per-iteration chain)
+    const double* pp = prep + (size_t)b * kLanPrep;
+    const double fro = pp[0], Mhi = pp[1], mlo = pp[2];
+    const bool quad_ok = pp[3] != 0.0;
+    const double q_shift = pp[4 + lane], q_weight = pp[4 + 64 + lane];
+    const double q_wres = q_weight / (mlo + q_shift);           // residual -> error weight of this lane's node
     if (tid == 0 && writer) fro_out[b] = fro;
     // ---- v_0 = b / ||b|| --------------------------------------------------------------------------------------------------
     double s2 = 0.0;
@@ -296,15 +384,22 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
         }
         return;
     }
+    if (!quad_ok) {                                             // spectrum bounds unusable (M/m beyond what the node table resolves)
+        if (writer) {
+            for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
+            if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
+        }
+        return;
+    }
     for (int i = tid; i < n; i += kLanThreads) { const double v = bv[i] / nrm_b; vcur[i] = v; if (nvl > 0) Vl[i] = v; else Vg[i] = v; }
     __syncthreads();
     const int mcap = n;
     int m = 0;
-    double Mhi = 0.0, mlo = 0.0, q_shift = 0.0, q_weight = 0.0, q_wres = 0.0, rd_prev = 1.0, g_prev = 0.0;   // quadrature node + pivot recurrence of this lane
+    double rd_prev = 1.0, g_prev = 0.0;                         // pivot recurrence of this lane's node
     for (int j = 0; j < mcap; ++j) {
         // ---- w = A v_j : lanes along rows (coalesced column reads), waves split the columns, kLanCG columns of loads in flight ----
-        double colmax = 0.0;
         LPROF(j, 0);
+        if (j == 0) LPROFG(2);
         if constexpr (COOP) {
             // own columns: w[c] = A[:, c] . v from the LDS slab, one wave per column (up to 3 columns per wave interleaved); the
             // reducing lane stores the entry to LDS and publishes it as a granule pair
@@ -318,7 +413,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                 __hip_atomic_store(&xp[2 * idx + 1], (bits >> 32) | thi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             for (int cb = c_lo + wv; cb < c_hi; cb += 3 * kLanWaves) {
-                double s0 = 0.0, s1 = 0.0, s2c = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+                double s0 = 0.0, s1 = 0.0, s2c = 0.0;
                 const int c1 = cb + kLanWaves, c2 = cb + 2 * kLanWaves;
                 for (int i = lane; i < n; i += 64) {
                     const double vi = vcur[i];
@@ -326,29 +421,20 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                     const double x1 = (c1 < c_hi) ? part_v[(size_t)(c1 - c_lo) * n + i] : 0.0;
                     const double x2 = (c2 < c_hi) ? part_v[(size_t)(c2 - c_lo) * n + i] : 0.0;
                     s0 = fma(x0, vi, s0); s1 = fma(x1, vi, s1); s2c = fma(x2, vi, s2c);
-                    if (j == 0) { a0 += fabs(x0); a1 += fabs(x1); a2 += fabs(x2); }
                 }
                 s0 = wave_sum(s0); s1 = wave_sum(s1); s2c = wave_sum(s2c);
-                if (j == 0) colmax = fmax(colmax, fmax(wave_sum(a0), fmax(wave_sum(a1), wave_sum(a2))));
                 if (lane == 0) {
                     wv_[cb] = s0; publish(cb, s0);
                     if (c1 < c_hi) { wv_[c1] = s1; publish(c1, s1); }
                     if (c2 < c_hi) { wv_[c2] = s2c; publish(c2, s2c); }
                 }
             }
-            if (j == 0) {                                        // ||A||_inf: the workgroup's column maximum travels with the first exchange
-                __syncthreads();
-                if (lane == 0) red[wv] = colmax;
-                __syncthreads();
-                if (tid == 0) { double t = 0.0; for (int w = 0; w < kLanWaves; ++w) t = fmax(t, red[w]); red[kLanWaves + 1 + 0] = t; publish(n + g, t); }
-            }
-            // the other workgroups' entries (and, at j = 0, their column maxima): one thread per entry polls its granule pair
+            // the other workgroups' entries: one thread per entry polls its granule pair
             LPROF(j, 1);
+            if (j == 0) LPROFG(3);
             int timed_out = 0;
-            const int nx = (j == 0) ? n + G : n;
-            for (int idx = tid; idx < nx; idx += kLanThreads) {
-                const bool own = (idx < n) ? (idx >= c_lo && idx < c_hi) : (idx - n == g);
-                if (own) continue;
+            for (int idx = tid; idx < n; idx += kLanThreads) {
+                if (idx >= c_lo && idx < c_hi) continue;
                 unsigned long long lo, hi;
                 const unsigned long long t0 = wall_clock64();
                 unsigned spins = 0;
@@ -360,17 +446,13 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const double v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
-                if (idx < n) wv_[idx] = v; else red[kLanWaves + 4 + (idx - n)] = v;
+                wv_[idx] = v;
             }
             if (__syncthreads_or(timed_out)) {                  // a partner is not running: the one-workgroup kernel queued behind this launch redoes the slot
                 if (tid == 0) { redo[b] = 1; atomicAdd(timeouts, 1); }
                 return;
             }
-            if (j == 0) {
-                double t = red[kLanWaves + 1];
-                for (int q = 0; q < G; ++q) if (q != g) t = fmax(t, red[kLanWaves + 4 + q]);
-                colmax = t;                                     // identical in every workgroup
-            }
+            if (j == 0) LPROFG(4);
         } else {
         for (int r0 = 0; r0 < n; r0 += 64 * kLanNQ) {
                 double acc[kLanNQ];
@@ -392,12 +474,6 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                         const double vc = (c < n) ? vcur[c] : 0.0;
 #pragma unroll
                         for (int q = 0; q < kLanNQ; ++q) acc[q] = fma(a[u][q], vc, acc[q]);
-                        if (j == 0 && c < n) {                                      // first pass: ||A||_inf (A symmetric: column abs sums)
-                            double sa = 0.0;
-#pragma unroll
-                            for (int q = 0; q < kLanNQ; ++q) if (r0 + lane + 64 * q < n) sa += fabs(a[u][q]);
-                            colmax = fmax(colmax, wave_sum(sa));                    // (exact for n <= 64 kLanNQ; larger n: per-chunk sums, see below)
-                        }
                     }
                 }
 #pragma unroll
@@ -411,31 +487,10 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                 wv_[i] = s;
             }
         }
-        if (j == 0) {
-            // M >= λ_max: max column abs sum; for n > 64 kLanNQ a column's sum is split over row chunks, so bound it by the number of
-            // chunks times the largest chunk sum (still an upper bound, only looser)
-            const int nchunk = COOP ? 1 : (n + 64 * kLanNQ - 1) / (64 * kLanNQ);
-            __syncthreads();
-            if (lane == 0) red[wv] = colmax;
-            __syncthreads();
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < kLanWaves; ++w) t = fmax(t, red[w]);
-            Mhi = t * nchunk;
-            mlo = fmin(1.0 / fro, 0.5 * Mhi);
-            if (!invsqrt_quad_node(mlo, Mhi, lane, 64, &q_shift, &q_weight)) {       // uniform: depends on mlo / Mhi only
-                if (writer) {
-                    for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-                    if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
-                }
-                return;
-            }
-            q_wres = q_weight / (mlo + q_shift);                 // residual -> error weight of this lane's node
-        }
-        __syncthreads();
+        if (!COOP) __syncthreads();
         LPROF(j, 2);
         // ---- orthogonalise against v_0..v_j twice (classical Gram-Schmidt, CGS2); α_j = the v_j coefficient -------------------
-        double a_j = 0.0;
+        double a_j = 0.0, w2 = 0.0;
         const int jl = min(j + 1, nvl);                                             // vectors 0 .. jl-1 in LDS, jl .. j in global memory
         for (int pass = 0; pass < 2; ++pass) {
             for (int k = wv; k <= j; k += kLanWaves) {
@@ -452,17 +507,28 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                 for (int k = 0; k < jl; ++k) s = fma(-coef[k], Vl[(size_t)k * n + i], s);
                 for (int k = jl; k <= j; ++k) s = fma(-coef[k], Vg[(size_t)k * n + i], s);
                 wv_[i] = s;
+                if (pass == 1) w2 = fma(s, s, w2);                                  // ||w||^2 of the final vector: the entries this thread has just written
             }
-            __syncthreads();
+            if (pass == 0) __syncthreads();
         }
         LPROF(j, 3);
-        double w2 = 0.0;
-        for (int i = tid; i < n; i += kLanThreads) { const double v = wv_[i]; w2 = fma(v, v, w2); }
-        const double bt = sqrt(block_sum(w2));
+        // β_j = ||w||: the barrier that publishes the second pass's w is the reduction's own (partials in the buffer of this step's parity: the previous
+        // reduction's readers are two barriers behind)
+        double bt;
+        {
+            const double v = wave_sum(w2);
+            if (lane == 0) red2[j & 1][wv] = v;
+            __syncthreads();
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kLanWaves; ++w) t += red2[j & 1][w];
+            bt = sqrt(t);
+        }
         if (tid == 0) { alpha[j] = a_j; beta[j] = bt; }
         m = j + 1;
         // ---- stopping rule, O(1): leading pivot d_m = α_m + s - β_{m-1}²/d_{m-1}, last solution component z_m = g_m = -β_{m-1} g_{m-1}/d_m
         //      (g_1 = 1/d_1); residual of node j's shifted system = β_m |z_m|, error <= sum_j w_j β_m |z_m| / (λ_min + s_j)  (per unit ||b||)
+        bool conv;
         {
             const double bprev = (j > 0) ? beta[j - 1] : 0.0;                        // written one step (and several barriers) ago
             const double d = a_j + q_shift - ((j > 0) ? bprev * bprev * rd_prev : 0.0);
@@ -470,12 +536,10 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             const double gcur = (j > 0) ? -bprev * g_prev * rd : rd;
             rd_prev = rd; g_prev = gcur;
             const double eb = bt * wave_sum(q_wres * fabs(gcur));
-            const bool conv = (eb <= kLanTol * (1.0 / sqrt(Mhi))) || (bt <= 1e-14 * Mhi) || (m >= mcap);
-            if (tid == 0) sh_flag = conv ? 1 : 0;
+            conv = (eb <= kLanTol * (1.0 / sqrt(Mhi))) || (bt <= 1e-14 * Mhi) || (m >= mcap);      // identical in every wave (same node table, same recurrences): no flag, no barrier
         }
-        __syncthreads();
         LPROF(j, 4);
-        if (sh_flag) break;
+        if (conv) break;
         const double rbt = fast_rcp(bt);
         for (int i = tid; i < n; i += kLanThreads) {
             const double v = wv_[i] * rbt;
@@ -528,16 +592,21 @@ int invsqrt_max_n() {
 // part[b][nb] = per-block-column partial sums of ||L^-1||_F^2 (only L is read: may run on another stream beside the sort / elite mean)
 size_t trtri_dinv_doubles(int B, int n) { return (size_t)B * ((n + kTB - 1) / kTB) * 256; }
 // hiprio = false: the launch runs beside a throughput kernel of the same handle (the rollout) and must not take its issue slots
-void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio) {
+size_t lanczos_prep_doubles(int B) { return (size_t)B * kLanPrep; }
+// A / scale / prep / sync2 (nullable together; sync2: [B][2] words, zero before the first launch): the slot's last workgroup also leaves the
+// Lanczos run's spectrum bounds and quadrature nodes in prep (lanczos_prep_slot)
+void launch_trtri_fro(const double* L, size_t Lstride, double* part, int B, int n, const int* active, hipStream_t s, double* dinv, bool hiprio,
+                      const double* A, const double* scale, double* prep, unsigned long long* sync2) {
     const int nb = (n + kTB - 1) / kTB;
     const size_t lds = ((size_t)(nb + 1) * 256 + 2 * kTriW * 256 + 2 * kTriW) * sizeof(double);
     static std::atomic<unsigned long long> seenp{0};
     ensure_dyn_lds((const void*)k_trtri_fro_pair<kTriW>, 150 * 1024, seenp);
     hipLaunchKernelGGL(k_trtri_diag, dim3(nb, B), dim3(64), 0, s, L, Lstride, n, nb, dinv, active, hiprio ? 1 : 0);
-    hipLaunchKernelGGL(k_trtri_fro_pair<kTriW>, dim3((nb + 1) / 2, B), dim3(128 * kTriW), lds, s, L, Lstride, n, nb, dinv, part, active, hiprio ? 1 : 0);
+    hipLaunchKernelGGL(k_trtri_fro_pair<kTriW>, dim3((nb + 1) / 2, B), dim3(128 * kTriW), lds, s, L, Lstride, n, nb, dinv, part, active, hiprio ? 1 : 0,
+                       A, scale, (prep && sync2) ? prep : nullptr, sync2);
 }
 
-// y = A^-1/2 b and fro = scale * sum(part) (the partial sums of launch_trtri_fro; 1/fro is also the quadrature's lower spectrum bound).
+// y = A^-1/2 b and fro = scale * sum(part) (prep: what launch_trtri_fro left for this A; 1/fro is also the quadrature's lower spectrum bound).
 // xbuf / epoch (nullable): exchange buffer (invsqrt_coop_words, zero-initialised once) and launch counter of the cooperative variant.
 size_t invsqrt_coop_words(int B, int n) { return (size_t)B * 4 * (n + 16); }
 int invsqrt_coop_groups(int B, int n, int share) {
@@ -548,10 +617,9 @@ int invsqrt_coop_groups(int B, int n, int share) {
     const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
     return (fixed + (size_t)4 * n) * sizeof(double) <= 150 * 1024 ? G : 1;
 }
-void launch_lanczos_invsqrt(const double* A, const double* scale, const double* bvec, size_t bstride, const double* part,
+void launch_lanczos_invsqrt(const double* A, const double* prep, const double* bvec, size_t bstride,
                             double* V, double* y, double* fro, int* msteps, int B, int n, int* status, const int* active, hipStream_t s,
                             int regions_per_slot, const CoopCtx& coop) {
-    const int nb = (n + kTB - 1) / kTB;
     static std::atomic<unsigned long long> seen2{0}, seen3{0};
     unsigned long long* const xbuf = coop.flags;
     const int G = coop.usable() ? std::min(invsqrt_coop_groups(B, n, coop.share), regions_per_slot) : 1;
@@ -566,14 +634,14 @@ void launch_lanczos_invsqrt(const double* A, const double* scale, const double* 
         ensure_dyn_lds((const void*)k_lanczos_invsqrt<true>, 150 * 1024, seen3);
         const unsigned long long ep = ++*coop.epoch;
         if ((ep & 0x3fffffull) == 0) (void)hipMemsetAsync(xbuf, 0, invsqrt_coop_words(B, n) * sizeof(unsigned long long), s);   // tag wrap: no stale granule may alias
-        hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl,
+        hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl,
                            status, active, G, regions_per_slot, xbuf, ep, coop.redo, coop.timeouts, coop_wait_ticks(), coop_test_drop());
         // slots whose cluster gave up (bounded waits): recomputed here by the kernel that needs no partner
-        hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl1,
+        hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl1,
                            status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, coop.redo, (int*)nullptr, 0ull, 0);
         return;
     }
-    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, part, nb, scale, V, y, fro, msteps, n, nvl1,
+    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl1,
                        status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, (int*)nullptr, (int*)nullptr, 0ull, 0);
 }
 

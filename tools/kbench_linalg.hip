@@ -87,28 +87,33 @@ int main(int argc, char** argv) {
     }
     if (getenv("KB_POTRF_ONLY")) return 0;
     double* ddinv; CK(hipMalloc(&ddinv, trtri_dinv_doubles(B, n) * 8));
-    printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv); }, 20, s));
+    double* dprep; CK(hipMalloc(&dprep, lanczos_prep_doubles(B) * 8));
+    unsigned long long* dcnt; CK(hipMalloc(&dcnt, B * 16)); CK(hipMemset(dcnt, 0, B * 16));
+    printf("trtri_fro             %8.1f us\n", timeit([&] { launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv, true, dA, nullptr, dprep, dcnt); }, 20, s));
     if (getenv("KB_LANCZOS_ONCE")) {
-        launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv);
+        launch_trtri_fro(dL, nn, dpart, B, n, dact, s, ddinv, true, dA, nullptr, dprep, dcnt);
+        for (int w = 0; w < 3; ++w) launch_lanczos_invsqrt(dA, dprep, db, n, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);     // warm
+        CK(hipStreamSynchronize(s));
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
+        launch_lanczos_invsqrt(dA, dprep, db, n, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
         hipEventRecord(e1, s); CK(hipStreamSynchronize(s)); float ms; hipEventElapsedTime(&ms, e0, e1);
         std::vector<int> m1(B), st1(B); CK(hipMemcpy(m1.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st1.data(), dstatus, B * 4, hipMemcpyDeviceToHost));
         printf("one lanczos launch (G = %d): %.3f ms, m[0] = %d, status[0] = %d\n", lanG, ms, m1[0], st1[0]);
 #ifdef POTRF_PROF
         { std::vector<unsigned long long> lp(64 * 8); mpopis::debug_read_lprof(lp.data()); const unsigned long long t00 = lp[0];
           printf("   step: start | matvec+publish | exchange | cgs2 | norm+stop | (us since kernel's first step)\n");
-          for (int j = 0; j <= m1[0] && j < 64; ++j) printf("   j=%2d %7.2f %7.2f %7.2f %7.2f %7.2f\n", j, (lp[j*8]-t00)*0.01, (lp[j*8+1]-t00)*0.01, (lp[j*8+2]-t00)*0.01, (lp[j*8+3]-t00)*0.01, (lp[j*8+4]-t00)*0.01); }
+          for (int g = 0; g < lanG && g < 8; ++g) printf("   workgroup %d: entry %7.2f slab loaded %7.2f loop %7.2f first mat-vec published %7.2f first exchange done %7.2f\n", g, (double)(long long)(lp[(48+g)*8]-t00)*0.01, (double)(long long)(lp[(48+g)*8+1]-t00)*0.01, (double)(long long)(lp[(48+g)*8+2]-t00)*0.01, (double)(long long)(lp[(48+g)*8+3]-t00)*0.01, (double)(long long)(lp[(48+g)*8+4]-t00)*0.01);
+          for (int j = 0; j <= m1[0] && j < 48; ++j) printf("   j=%2d %7.2f %7.2f %7.2f %7.2f %7.2f\n", j, (lp[j*8]-t00)*0.01, (lp[j*8+1]-t00)*0.01, (lp[j*8+2]-t00)*0.01, (lp[j*8+3]-t00)*0.01, (lp[j*8+4]-t00)*0.01); }
 #endif
         std::vector<unsigned long long> xb(4 * (n + lanG)); CK(hipMemcpy(xb.data(), dlx, xb.size() * 8, hipMemcpyDeviceToHost));
         for (int i : {0, 1, 37, 38, 39, 150, 299, 300, 301, 307}) if (i < n + lanG) printf("   x[%d] = %016llx %016llx | parity1 %016llx %016llx\n", i, xb[2 * i], xb[2 * i + 1], xb[2 * (n + lanG) + 2 * i], xb[2 * (n + lanG) + 2 * i + 1]);
         return 0;
     }
-    printf("lanczos (G = %d)       %8.1f us\n", lanG, timeit([&] { launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc); }, 20, s));
+    printf("lanczos (G = %d)       %8.1f us\n", lanG, timeit([&] { launch_lanczos_invsqrt(dA, dprep, db, n, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc); }, 20, s));
     {   // y against the one-workgroup kernel
         std::vector<double> y1((size_t)B * n), y0((size_t)B * n);
         CK(hipMemcpy(y1.data(), dy, y1.size() * 8, hipMemcpyDeviceToHost));
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, 1, CoopCtx());
+        launch_lanczos_invsqrt(dA, dprep, db, n, dV, dy, dfro, dm, B, n, dstatus, dact, s, 1, CoopCtx());
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(y0.data(), dy, y0.size() * 8, hipMemcpyDeviceToHost));
         double d = 0, nr = 0; for (size_t i = 0; i < y0.size(); ++i) { d = fmax(d, fabs(y1[i] - y0[i])); nr = fmax(nr, fabs(y0[i])); }
@@ -116,8 +121,8 @@ int main(int argc, char** argv) {
     }
     {   // applying the operator twice must invert A: y2 = A^-1/2 (A^-1/2 b) = A^-1 b  ->  ||A y2 - b|| / ||b||
         double* dy2; CK(hipMalloc(&dy2, (size_t)B * n * 8));
-        launch_lanczos_invsqrt(dA, nullptr, db, n, dpart, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
-        launch_lanczos_invsqrt(dA, nullptr, dy, n, dpart, dV, dy2, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
+        launch_lanczos_invsqrt(dA, dprep, db, n, dV, dy, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
+        launch_lanczos_invsqrt(dA, dprep, dy, n, dV, dy2, dfro, dm, B, n, dstatus, dact, s, lanG, lc);
         CK(hipStreamSynchronize(s));
         std::vector<double> y2((size_t)B * n); CK(hipMemcpy(y2.data(), dy2, y2.size() * 8, hipMemcpyDeviceToHost));
         double worst = 0;
