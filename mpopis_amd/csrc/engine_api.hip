@@ -903,8 +903,10 @@ int mpopis_handle::step_enqueue_view(bool injected, hipEvent_t wait_first, hipEv
     // (C5, 64 trials: 6.72 vs 6.45 ms per step: the drawing then competes with the moments kernel instead of filling the MFMA bubbles of
     // the fused kernel); MPOPIS_ZPREFETCH=2 forces it for such A/B runs, 0 disables it.
     static const int env_zpre = [] { const char* e = getenv("MPOPIS_ZPREFETCH"); return e ? atoi(e) : 1; }();
-    const bool z_prefetch_ok = env_zpre && (env_zpre == 2 || !sample_trmm_fusable(cs)) && side_free && xstream[1] && !injected && pol != MPOPIS_POL_MPPI && pol != MPOPIS_POL_PMCMPPI /* d_Z holds E[:, idx] there */ &&
-                               !(sigma_diag && sigma_fixed) && N > 1;
+    // (the fork and the wait are two packets of ~6 us each on the main stream: below ~4 M normals per draw -- one or two C4 trials, an 8-12 us kernel -- drawing in line is
+    // shorter: 4.20 -> 4.165 ms per C4 step at one trial, 4.55 -> 4.525 at two, neutral at four, +1 % at eight)
+    const bool z_prefetch_ok = env_zpre && (env_zpre == 2 || (!sample_trmm_fusable(cs) && (size_t)B * cs * K >= (size_t)4000000)) && side_free && xstream[1] && !injected &&
+                               pol != MPOPIS_POL_MPPI && pol != MPOPIS_POL_PMCMPPI /* d_Z holds E[:, idx] there */ && !(sigma_diag && sigma_fixed) && N > 1;
     bool z_prefetched = false;
     for (int n = 1; n <= N; ++n) {
         // ---- P = MvNormal(Σ′): Cholesky; Σ_inv only through gvec --------------------------------

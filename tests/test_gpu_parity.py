@@ -507,6 +507,30 @@ def test_cma_posdef_error_matches_reference_behaviour(eng_mod, oracle, track):
     eng.close()
 
 
+@pytest.mark.parametrize("ncars,T", [(1, 10), (3, 50)])
+def test_cma_numeric_error_when_the_spectrum_is_beyond_the_quadrature(eng_mod, track, ncars, T):
+    """:cmamppi forms Σ^-0.5 δw (:580-581) with a 64-node quadrature of x^-1/2 on [m, M] (m = 1 / tr(Σ^-1), M = ||Σ||_inf) that resolves m / M down to
+    1e-14.  A proposal covariance beyond that (here diag entries 1 and 1e-16: its Cholesky factor exists) must be reported as MPOPIS_ERR_NUMERIC (-5)
+    -- the bounds and nodes are prepared by the last workgroup of the L^-1 trace launch (kernels_invsqrt.hip, lanczos_prep_slot), which has to hand the
+    verdict to the Lanczos kernel -- and the handle must keep working once a usable covariance is set (cs = 20: one workgroup; cs = 300: register
+    Cholesky + clusters)."""
+    from mpopis_amd._lib import MPOPISError
+    cs = 2 * ncars * T
+    K = 256
+    eng = eng_mod.Engine("car", ncars, "cmamppi", K, T, batch=2, lam=10.0, ais_its=3, cma_sigma=0.75, cov=np.tile([0.0625, 0.1], ncars), track=track, seed=5)
+    d = np.ones(cs)
+    d[cs // 2] = 1e-16
+    eng.set_Sigma(np.diag(d))
+    with pytest.raises(MPOPISError) as ei:
+        eng.policy_step(None)
+    assert ei.value.code == -5, str(ei.value)
+    eng.reset()
+    eng.set_Sigma(np.diag(np.tile([0.0625, 0.1], cs // 2)))
+    got = eng.policy_step(None)
+    assert np.all(np.isfinite(got["control"])) and np.all(got["iters_run"] >= 1)
+    eng.close()
+
+
 def test_other_track_through_loader(eng_mod, oracle, tmp_path):
     """Track(infile; width, sample_factor) with a different centre line (ellipse, 640 points, sample_factor 8, width 9):
     variable P / lane width reach the kernels through the ABI (car_racing_tracks.jl:14-34)."""
