@@ -306,23 +306,14 @@ void debug_read_lprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LPROF(j_, k_) do { } while (0)
 #define LPROFG(k_) do { } while (0)
 #endif
+// returns 1 when a cluster member gave up waiting for its partners (COOP only; the caller lets workgroup 0 of the cluster redo the slot alone), else 0
 template <bool COOP>
-__global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
-                                                                 const double* __restrict__ prep,
-                                                                 double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
-                                                                 int* __restrict__ msteps, int n, int nvl, int* status, const int* active,
-                                                                 int G, int Gs, unsigned long long* xbuf, unsigned long long epoch, int* redo, int* timeouts,
-                                                                 unsigned long long wait_ticks, int test_drop) {
-    MPOPIS_HI_PRIO();
-    const int b = COOP ? blockIdx.x / G : blockIdx.x, g = COOP ? blockIdx.x % G : 0;
-    if (!COOP && redo) {                                        // fall-back pass behind the cooperative launch: only the slots whose cluster gave up
-        if (!redo[b]) return;                                   // (the common case: nothing to do)
-        __syncthreads();
-        if (threadIdx.x == 0) redo[b] = 0;
-    }
-    if (active && !active[b]) return;
-    LPROFG(0);
-    if (COOP && test_drop && g == G - 1) return;                // test hook: a partner that never runs
+__device__ __forceinline__ int lanczos_run(const int b, const int g, const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
+                                           const double* __restrict__ prep,
+                                           double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
+                                           int* __restrict__ msteps, int n, int nvl, int* status,
+                                           int G, int Gs, unsigned long long* xbuf, unsigned long long epoch, int* timeouts,
+                                           unsigned long long wait_ticks) {
     extern __shared__ __attribute__((aligned(16))) double sh_lan[];
     const int nc = COOP ? (n + G - 1) / G : 0, c_lo = g * nc, c_hi = min(n, c_lo + nc);       // own columns (COOP)
     double* part_v = sh_lan;                            // [kLanWaves][n]  (COOP: the column slab [nc][n])
@@ -382,14 +373,14 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
             for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
             if (tid == 0) { msteps[b] = 0; if (nrm_b > 0.0 || !(nrm_b == nrm_b)) status_raise(&status[b], MPOPIS_ERR_NUMERIC); }      // never hides an earlier error of the slot
         }
-        return;
+        return 0;
     }
     if (!quad_ok) {                                             // spectrum bounds unusable (M/m beyond what the node table resolves)
         if (writer) {
             for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
             if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
         }
-        return;
+        return 0;
     }
     for (int i = tid; i < n; i += kLanThreads) { const double v = bv[i] / nrm_b; vcur[i] = v; if (nvl > 0) Vl[i] = v; else Vg[i] = v; }
     __syncthreads();
@@ -448,9 +439,9 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
                 const double v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
                 wv_[idx] = v;
             }
-            if (__syncthreads_or(timed_out)) {                  // a partner is not running: the one-workgroup kernel queued behind this launch redoes the slot
-                if (tid == 0) { redo[b] = 1; atomicAdd(timeouts, 1); }
-                return;
+            if (__syncthreads_or(timed_out)) {                  // a partner is not running: workgroup 0 of this cluster redoes the slot alone (k_lanczos_invsqrt)
+                if (tid == 0) atomicAdd(timeouts, 1);
+                return 1;
             }
             if (j == 0) LPROFG(4);
         } else {
@@ -579,6 +570,32 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     }
     if (tid == 0 && writer) msteps[b] = m;
     LPROF(m, 1);
+    return 0;
+}
+
+// COOP = true: G workgroups per slot.  A cluster whose members do not all run (bounded waits) is redone by its workgroup 0 with the one-workgroup
+// algorithm IN THIS LAUNCH (same LDS allocation, laid out for one workgroup: nvl_solo basis vectors) -- until round 5 a second launch of the
+// one-workgroup kernel, predicated on a per-slot flag, was queued behind every cluster launch for that: 6 us on the per-iteration chain for a kernel
+// that did nothing.
+template <bool COOP>
+__global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
+                                                                 const double* __restrict__ prep,
+                                                                 double* __restrict__ Vall, double* __restrict__ yall, double* __restrict__ fro_out,
+                                                                 int* __restrict__ msteps, int n, int nvl, int nvl_solo, int* status, const int* active,
+                                                                 int G, int Gs, unsigned long long* xbuf, unsigned long long epoch, int* timeouts,
+                                                                 unsigned long long wait_ticks, int test_drop) {
+    MPOPIS_HI_PRIO();
+    const int b = COOP ? blockIdx.x / G : blockIdx.x, g = COOP ? blockIdx.x % G : 0;
+    if (active && !active[b]) return;
+    LPROFG(0);
+    if (COOP && test_drop && g == G - 1) return;                // test hook: a partner that never runs
+    const int rc = lanczos_run<COOP>(b, g, Aall, bvec, bstride, prep, Vall, yall, fro_out, msteps, n, nvl, status, G, Gs, xbuf, epoch, timeouts, wait_ticks);
+    if constexpr (COOP) {
+        if (rc && g == 0) {
+            __syncthreads();
+            (void)lanczos_run<false>(b, 0, Aall, bvec, bstride, prep, Vall, yall, fro_out, msteps, n, nvl_solo, status, 1, Gs, nullptr, 0ull, nullptr, 0ull);
+        }
+    }
 }
 
 size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot) { return (size_t)B * regions_per_slot * (size_t)(n + 1 + 128) * n; }   // cooperative runs: one spill region per workgroup
@@ -623,26 +640,25 @@ void launch_lanczos_invsqrt(const double* A, const double* prep, const double* b
     static std::atomic<unsigned long long> seen2{0}, seen3{0};
     unsigned long long* const xbuf = coop.flags;
     const int G = coop.usable() ? std::min(invsqrt_coop_groups(B, n, coop.share), regions_per_slot) : 1;
-    const size_t fixed1 = (size_t)(kLanWaves + 6) * n + 1 + kLanRed + 2 * kLanPivLds * 64;              // doubles (one-workgroup kernel)
-    const int nvl1 = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed1) / n);          // basis vectors that fit next to it
-    const size_t lds1 = (fixed1 + (size_t)nvl1 * n) * sizeof(double);
-    ensure_dyn_lds((const void*)k_lanczos_invsqrt<false>, 150 * 1024, seen2);
+    const size_t fixed1 = (size_t)(kLanWaves + 6) * n + 1 + kLanRed + 2 * kLanPivLds * 64;              // doubles (one-workgroup layout)
     if (G > 1) {
         const size_t fixed = (size_t)6 * n + 1 + kLanRed + 2 * kLanPivLds * 64 + (size_t)((n + G - 1) / G) * n;
         const int nvl = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed) / n);
         const size_t lds = (fixed + (size_t)nvl * n) * sizeof(double);
+        // the cluster's own fall-back (its workgroup 0 alone, one-workgroup layout in the same allocation)
+        const int nvl_solo = lds / sizeof(double) > fixed1 ? (int)std::min<size_t>(n + 1, (lds / sizeof(double) - fixed1) / n) : 0;
         ensure_dyn_lds((const void*)k_lanczos_invsqrt<true>, 150 * 1024, seen3);
         const unsigned long long ep = ++*coop.epoch;
         if ((ep & 0x3fffffull) == 0) (void)hipMemsetAsync(xbuf, 0, invsqrt_coop_words(B, n) * sizeof(unsigned long long), s);   // tag wrap: no stale granule may alias
-        hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl,
-                           status, active, G, regions_per_slot, xbuf, ep, coop.redo, coop.timeouts, coop_wait_ticks(), coop_test_drop());
-        // slots whose cluster gave up (bounded waits): recomputed here by the kernel that needs no partner
-        hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl1,
-                           status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, coop.redo, (int*)nullptr, 0ull, 0);
+        hipLaunchKernelGGL(k_lanczos_invsqrt<true>, dim3(B * G), dim3(kLanThreads), lds, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl, nvl_solo,
+                           status, active, G, regions_per_slot, xbuf, ep, coop.timeouts, coop_wait_ticks(), coop_test_drop());
         return;
     }
-    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl1,
-                       status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, (int*)nullptr, (int*)nullptr, 0ull, 0);
+    const int nvl1 = (int)std::min<size_t>(n + 1, (150 * 1024 / sizeof(double) - fixed1) / n);          // basis vectors that fit next to it
+    const size_t lds1 = (fixed1 + (size_t)nvl1 * n) * sizeof(double);
+    ensure_dyn_lds((const void*)k_lanczos_invsqrt<false>, 150 * 1024, seen2);
+    hipLaunchKernelGGL(k_lanczos_invsqrt<false>, dim3(B), dim3(kLanThreads), lds1, s, A, bvec, bstride, prep, V, y, fro, msteps, n, nvl1, nvl1,
+                       status, active, 1, regions_per_slot, (unsigned long long*)nullptr, 0ull, (int*)nullptr, 0ull, 0);
 }
 
 }  // namespace mpopis
