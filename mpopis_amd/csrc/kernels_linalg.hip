@@ -104,25 +104,8 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
             if (i >= c) W[(size_t)i + (size_t)c * ldw] -= acc[r];
         }
     };
-    // (the barriers of the panel loop wait for LDS only: the output stores below drain behind the arithmetic, nothing here reads them back)
-    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    double* Lp = Lpanel ? Lpanel + (size_t)b * pstride : nullptr;
-    // the 16 columns of a finished panel go out at once -- L with its zeros above the diagonal, and the sampler's panel copy of the same chunk -- by the
-    // waves that are not factoring the next diagonal block, behind their share of the trailing update: at the end of the kernel only the last panel is left
-    // (the whole 80 + 114 KB used to be stored after the last panel: ~4 us of a 30 us kernel at n = 100)
-    auto store_panel = [&](int j0, int w0, int nwv) {
-        for (int j = j0 + wv - w0; j < min(j0 + kNB, n); j += nwv)
-            for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
-        if (Lp) {
-            for (int e = (wv - w0) * 64 + lane; e < 16 * kPanelRows; e += nwv * 64) {
-                const int i = e & (kPanelRows - 1), pr = e / kPanelRows;
-                const int j = j0 + (pr & 3) * 4 + (pr >> 2);                  // p = (jc & 3) 4 + (jc >> 2)  <=>  jc = 4 (p & 3) + (p >> 2)
-                Lp[(size_t)(j0 / 16) * 16 * kPanelRows + e] = (i < n && j < n && i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
-            }
-        }
-    };
     if (wv == 0) factor_diag_inv(0);
-    lds_barrier();
+    __syncthreads();
     for (int j0 = 0; j0 < m; j0 += kNB) {
         if (failed) break;
         const int i1 = j0 + kNB, ntile = (m - i1) / 16, t1 = i1 / 16;
@@ -130,15 +113,29 @@ __global__ void __launch_bounds__(512) k_potrf_lds(const double* __restrict__ A,
             const PanelOps o = panel_solve_operands(lane, dsh);
             for (int t = wv; t < ntile; t += NW) panel_tile(o, j0, i1 + 16 * t);
         }
-        lds_barrier();
+        __syncthreads();
         if (ntile > 0) {
             const int npair = ntile * (ntile + 1) / 2;
             if (wv == 0) { trail_pair(j0, t1, 0); factor_diag_inv(i1); }         // look-ahead: next diagonal block while the others update
-            else { for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q); store_panel(j0, 1, NW - 1); }
-        } else store_panel(j0, 0, NW);                                         // the last panel: everybody
-        lds_barrier();
+            else for (int q = wv; q < npair; q += NW - 1) trail_pair(j0, t1, q);
+        }
+        __syncthreads();
     }
-    if (failed && tid == 0) { if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+    if (failed) {
+        if (tid == 0) { if (status) status_raise(&status[b], MPOPIS_ERR_NOT_PD); if (active) active[b] = 0; }
+        return;
+    }
+    for (int j = wv; j < n; j += NW)
+        for (int i = lane; i < n; i += 64) Lb[(size_t)i + (size_t)j * n] = (i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
+    if (Lpanel) {
+        double* Lp = Lpanel + (size_t)b * pstride;
+        const int nch = (n + 15) / 16;
+        for (int e = tid; e < nch * 16 * kPanelRows; e += NTHR) {
+            const int i = e & (kPanelRows - 1), pr = (e / kPanelRows) & 15, c = e / (16 * kPanelRows);
+            const int j = c * 16 + (pr & 3) * 4 + (pr >> 2);                  // p = (jc & 3) 4 + (jc >> 2)  <=>  jc = 4 (p & 3) + (p >> 2)
+            Lp[e] = (i < n && j < n && i >= j) ? W[(size_t)i + (size_t)j * ldw] : 0.0;
+        }
+    }
 }
 
 // Global-memory variant for matrices that do not fit in LDS (cs = 300: three cars), one workgroup of 16 waves: the working

@@ -17,9 +17,9 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {     // src is 
 // 4g .. 4g+3, loaded through `load(i, c)` (identity beyond the matrix edge; only i >= c is used).  A lone wave issues an FP64
 // instruction only every ~8 cycles whatever its dependencies, so the cost is the instruction count: the block is processed as a
 // 4 x 4 grid of 4x4 sub-blocks with ONE LDS exchange per sub-block column G.  Per G: every lane gathers the diagonal 4x4
-// sub-block (v_readlane), factors it redundantly in registers (and, off the chain, inverts it for the panel solve) (rsqrt: v_rsq_f64 + one Newton step, <= 2 ulp --
+// sub-block (v_readlane), factors it and inverts it redundantly in registers (rsqrt: v_rsq_f64 + one Newton step, <= 2 ulp --
 // the error rescales the whole column consistently, |L L' - A| stays at rounding level), the lanes of column group G turn their
-// row into L (forward substitution against the sub-block's factor), the L column block goes through LDS and every lane updates its trailing entries.
+// row into L (rows below: x T', T = L4^-1), the L column block goes through LDS and every lane updates its trailing entries.
 // Out: the factor through `store(i, c, v)` (c <= i) and, for the panel solve that follows (panel_solve_tile), sh.L = the factor
 // with zeros above the diagonal and sh.T[G] = the inverses of the four diagonal 4x4 sub-blocks.  Returns true on a non-positive pivot.
 struct DiagScratch { double Lc[2][kNB][5], T[4][4][4], L[kNB][kNB + 1]; };
@@ -49,40 +49,37 @@ __device__ __forceinline__ bool diag16_factor(int lane, LoadF load, StoreF store
         const double s20 = bcast_lane(e[0], 4 * G + 2 + 16 * G), s21 = bcast_lane(e[1], 4 * G + 2 + 16 * G), s22 = bcast_lane(e[2], 4 * G + 2 + 16 * G);
         const double s30 = bcast_lane(e[0], 4 * G + 3 + 16 * G), s31 = bcast_lane(e[1], 4 * G + 3 + 16 * G), s32 = bcast_lane(e[2], 4 * G + 3 + 16 * G),
                      s33 = bcast_lane(e[3], 4 * G + 3 + 16 * G);
-        // Cholesky of the sub-block, wave-uniform: only what the rows need -- the reciprocal pivots and the off-diagonal entries (the diagonal entries
-        // come out of the rows' own substitution below with the same bits: l_rr = d_r r_r)
-        const double r0 = rsqrt1(s00), l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
-        const double d1 = fma(-l10, l10, s11), r1 = rsqrt1(d1);
+        // Cholesky of the sub-block and its inverse T (both lower triangular), in registers
+        const double r0 = rsqrt1(s00), l00 = s00 * r0, l10 = s10 * r0, l20 = s20 * r0, l30 = s30 * r0;
+        const double d1 = fma(-l10, l10, s11), r1 = rsqrt1(d1), l11 = d1 * r1;
         const double l21 = fma(-l20, l10, s21) * r1, l31 = fma(-l30, l10, s31) * r1;
-        const double d2 = fma(-l21, l21, fma(-l20, l20, s22)), r2 = rsqrt1(d2);
+        const double d2 = fma(-l21, l21, fma(-l20, l20, s22)), r2 = rsqrt1(d2), l22 = d2 * r2;
         const double l32 = fma(-l31, l21, fma(-l30, l20, s32)) * r2;
-        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33))), r3 = rsqrt1(d3);
-        // (b) column block G of L: every row of the column group solves x L4' = its four entries by forward substitution -- for the rows of the
-        // sub-block itself that IS the factor's row (entries right of the diagonal: zero), rows above the sub-block are zero.  10 FMA-class operations and three
-        // selects per lane (round 4: the explicit inverse T first, x T' for the rows below and one-hot weights for the rows inside: 42, all on the chain)
+        const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, s33))), r3 = rsqrt1(d3), l33 = d3 * r3;
+        const double t00 = r0, t11 = r1, t22 = r2, t33 = r3;
+        const double t10 = -(l10 * t00) * r1, t21 = -(l21 * t11) * r2, t32 = -(l32 * t22) * r3;
+        const double t20 = -fma(l21, t10, l20 * t00) * r2, t31 = -fma(l32, t21, l31 * t11) * r3;
+        const double t30 = -fma(l32, t20, fma(l31, t10, l30 * t00)) * r3;
+        if (lane == 0) {                                        // wave-uniform values: one lane stores T_G (zeros above its diagonal)
+            double* Tg = &sh.T[G][0][0];
+            Tg[0] = t00; Tg[1] = 0.0; Tg[2] = 0.0; Tg[3] = 0.0;
+            Tg[4] = t10; Tg[5] = t11; Tg[6] = 0.0; Tg[7] = 0.0;
+            Tg[8] = t20; Tg[9] = t21; Tg[10] = t22; Tg[11] = 0.0;
+            Tg[12] = t30; Tg[13] = t31; Tg[14] = t32; Tg[15] = t33;
+        }
+        // (b) column block G of L: the sub-block rows take L4, rows below x T' (x = the row's four entries), rows above 0 --
+        // branch-free: one-hot row weights (a 6-way branch costs more scalar bookkeeping than the 14 extra FMAs)
         if (g == G) {
             const int r = i - 4 * G;
-            const double x0 = e[0] * r0;
-            const double x1 = fma(-x0, l10, e[1]) * r1;
-            const double x2 = fma(-x1, l21, fma(-x0, l20, e[2])) * r2;
-            const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, e[3]))) * r3;
-            e[0] = (r >= 0) ? x0 : 0.0; e[1] = (r >= 1) ? x1 : 0.0; e[2] = (r >= 2) ? x2 : 0.0; e[3] = (r >= 3) ? x3 : 0.0;
-            if (G < 3) { Lc[buf][i][0] = e[0]; Lc[buf][i][1] = e[1]; Lc[buf][i][2] = e[2]; Lc[buf][i][3] = e[3]; }
-        }
-        // the inverse T of the sub-block for the panel solve that follows (panel_solve_tile): not needed by anything in this routine any more, so its 16
-        // operations sit behind the column block's LDS write -- in the shadow of the exchange's latency instead of on the chain to the next round
-        {
-            const double t00 = r0, t11 = r1, t22 = r2, t33 = r3;
-            const double t10 = -(l10 * t00) * r1, t21 = -(l21 * t11) * r2, t32 = -(l32 * t22) * r3;
-            const double t20 = -fma(l21, t10, l20 * t00) * r2, t31 = -fma(l32, t21, l31 * t11) * r3;
-            const double t30 = -fma(l32, t20, fma(l31, t10, l30 * t00)) * r3;
-            if (lane == 0) {                                    // wave-uniform values: one lane stores T_G (zeros above its diagonal)
-                double* Tg = &sh.T[G][0][0];
-                Tg[0] = t00; Tg[1] = 0.0; Tg[2] = 0.0; Tg[3] = 0.0;
-                Tg[4] = t10; Tg[5] = t11; Tg[6] = 0.0; Tg[7] = 0.0;
-                Tg[8] = t20; Tg[9] = t21; Tg[10] = t22; Tg[11] = 0.0;
-                Tg[12] = t30; Tg[13] = t31; Tg[14] = t32; Tg[15] = t33;
-            }
+            const double w0 = (r == 0) ? 1.0 : 0.0, w1 = (r == 1) ? 1.0 : 0.0, w2 = (r == 2) ? 1.0 : 0.0, w3 = (r == 3) ? 1.0 : 0.0,
+                         wb = (r > 3) ? 1.0 : 0.0;
+            const double x0 = wb * e[0], x1 = wb * e[1], x2 = wb * e[2], x3 = wb * e[3];
+            const double n0 = fma(w3, l30, fma(w2, l20, fma(w1, l10, fma(w0, l00, x0 * t00))));
+            const double n1 = fma(w3, l31, fma(w2, l21, fma(w1, l11, fma(x1, t11, x0 * t10))));
+            const double n2 = fma(w3, l32, fma(w2, l22, fma(x2, t22, fma(x1, t21, x0 * t20))));
+            const double n3 = fma(w3, l33, fma(x3, t33, fma(x2, t32, fma(x1, t31, x0 * t30))));
+            e[0] = n0; e[1] = n1; e[2] = n2; e[3] = n3;
+            if (G < 3) { Lc[buf][i][0] = n0; Lc[buf][i][1] = n1; Lc[buf][i][2] = n2; Lc[buf][i][3] = n3; }
         }
         if (G < 3) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
