@@ -365,8 +365,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)       # (the round driver runs `bench.py --gpus 1 --steps 20 --warmup 5`: same as the defaults)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trials-per-gpu", type=int, default=TRIALS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=100, help="extra repetitions of the timed region (after it), for median / min / max")

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/$TAG
 mkdir -p "$O"
-cd "$R" && python bench.py > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"
+cd "$R" && python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_line.json" 2> "$O/bench.err"; tail -c 1500 "$O/bench_line.json"      # the driver's command (BENCH_rNN.json: cmd)
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations need the chip to themselves: the profiled passes pin the schedule to ONE stream (MPOPIS_NSPLIT=1 = mpopis_set_overlap(h, 1),
 # what bench.py's own one-stream pass does for roofline.frac); the default schedule for this shape is four part-chains that time-share the chip.
