@@ -66,3 +66,4 @@ def _check(harness, B, n, env):
     assert _num(r"lanczos coop vs single: max \|dy\| = ([0-9.e+-]+)", t) < 1e-11 * ymax
     assert _num(r"invsqrt applied twice: .* = ([0-9.e+-]+)", t) < 1e-9
     assert _num(r"status (-?\d+), tr", t) == 0
+    assert _num(r"lanczos prep vs host: max rel ([0-9.e+-]+)", t) < 1e-12 and _num(r"usable (\d)", t) == 1   # spectrum bounds / quadrature nodes left by the trace launch

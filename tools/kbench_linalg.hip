@@ -1,6 +1,7 @@
 // kbench_linalg.hip -- standalone timing of the one-workgroup-per-slot linear-algebra kernels at CMA sizes (dev tool, not shipped).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench_linalg.hip mpopis_amd/lib/obj/kernels_linalg.o mpopis_amd/lib/obj/kernels_invsqrt.o -o tools/kbench_linalg_bin
 #include "../mpopis_amd/csrc/engine.h"
+#include "../mpopis_amd/csrc/invsqrt_quad.h"
 #include <cstdio>
 #include <vector>
 #include <random>
@@ -139,6 +140,27 @@ int main(int argc, char** argv) {
         const int np = (n + 15) / 16; std::vector<double> pp(np); CK(hipMemcpy(pp.data(), dpart, np * 8, hipMemcpyDeviceToHost));
         double trd = 0; for (double v : pp) trd += v;
         printf("   trtri_fro: ||L^-1||_F^2 device %.12e host %.12e rel %.2e\n", trd, tr, fabs(trd - tr) / tr);
+    }
+    {   // what the trace launch's last workgroup left for the Lanczos kernel (lanczos_prep_slot), against the host: fro = sum of the partial traces,
+        // M = max column abs sum, m = min(1 / fro, M / 2), the 64 quadrature nodes of invsqrt_quad.h for [m, M] (host libm vs device sin / asin: rounding-level apart)
+        const int np = (n + 15) / 16, NP = 4 + 128;
+        std::vector<double> pr((size_t)B * NP), pall((size_t)B * np);
+        CK(hipMemcpy(pr.data(), dprep, pr.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(pall.data(), dpart, pall.size() * 8, hipMemcpyDeviceToHost));
+        double worst = 0; int usable = 1;
+        for (int bb = 0; bb < B; ++bb) {
+            double fr = 0; for (int J = 0; J < np; ++J) fr += pall[(size_t)bb * np + J];
+            double M = 0; for (int c = 0; c < n; ++c) { double a = 0; for (int i = 0; i < n; ++i) a += fabs(A[bb * nn + i + (size_t)c * n]); M = fmax(M, a); }
+            const double* o = &pr[(size_t)bb * NP];
+            const double mlo = fmin(1.0 / fr, 0.5 * M);
+            worst = fmax(worst, fmax(fabs(o[0] - fr) / fr, fmax(fabs(o[1] - M) / M, fabs(o[2] - mlo) / mlo)));
+            usable &= (o[3] == 1.0);
+            for (int j = 0; j < 64; ++j) {
+                double sh, wt;
+                if (!invsqrt_quad_node(o[2], o[1], j, 64, &sh, &wt)) { usable = 0; break; }
+                worst = fmax(worst, fmax(fabs(o[4 + j] - sh) / sh, fabs(o[4 + 64 + j] - wt) / wt));
+            }
+        }
+        printf("   lanczos prep vs host: max rel %.3e, usable %d\n", worst, usable);
     }
     std::vector<int> m(B), st(B); std::vector<double> fro(B);
     CK(hipMemcpy(m.data(), dm, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(st.data(), dstatus, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(fro.data(), dfro, B * 8, hipMemcpyDeviceToHost));
