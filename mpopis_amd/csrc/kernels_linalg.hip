@@ -672,6 +672,22 @@ __global__ void __launch_bounds__(kCoopThreads) k_potrf_coop(const double* __res
     // (pending is never left set: the last panel has no successor, so it is published at once)
 }
 
+// k_potrf_reg needs nearly a whole CU's LDS (strip + tile slots + ~6 KB static: 158.4 KB at n = 304 of the 160 KB a workgroup may have on gfx950); asked of the
+// device once per ordinal, so that a part with less falls back to the cluster / one-workgroup kernels instead of failing to launch
+static bool potrf_reg_fits_device() {
+    static std::atomic<int> ok[64];                             // 0 unknown, 1 fits, 2 does not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int v = ok[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int lds = 0;
+        const bool got = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
+        v = (got && (size_t)lds >= potrf_reg_lds_bytes(kRegMaxPan * kNB) + sizeof(DiagScratch) + sizeof(double) * kNB * (kNB + 1) + 64) ? 1 : 2;      // + the kernel's static LDS
+        ok[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
 size_t potrf_coop_flag_words(int B, int n) { return (size_t)B * ((n + kNB - 1) / kNB); }
 
 // coop_flags / coop_epoch: per-handle workspace (potrf_coop_flag_words, zero-initialised once) and launch counter; null -> never cooperative
@@ -713,7 +729,7 @@ void launch_potrf(const double* A, size_t Astride, double* L, int B, int n, cons
     static const int env_reg = [] { const char* e = getenv("MPOPIS_POTRF_REG"); return e ? atoi(e) : 1; }();      // tests / A-B: 0 = the cluster and global kernels only
     // n = 241 .. 304: the register-resident kernel (n = 300: 133 us at one slot, 140 us at 64 -- clusters 160, one-workgroup global 225; below 16 panels
     // its fixed costs -- 8 us of loads through one CU, ~5 us per panel whatever its height -- lose to the clusters: n = 240: 123 vs 120, n = 144: 84 vs 68)
-    if (env_reg && npan >= kRegMinPan && npan <= kRegMaxPan) {
+    if (env_reg && npan >= kRegMinPan && npan <= kRegMaxPan && potrf_reg_fits_device()) {
         static std::atomic<unsigned long long> seenr{0};
         const size_t rbytes = potrf_reg_lds_bytes(n);
         ensure_dyn_lds((const void*)k_potrf_reg, (int)potrf_reg_lds_bytes(kRegMaxPan * kNB), seenr);
