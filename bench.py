@@ -36,6 +36,101 @@ BYTES_PER_ROLLOUT = 8 * (4 * 2 * CARS * H + 4)      # 3232 B (Σ-ad
 FLOPS_PER_ROLLOUT = 3.5e5 * CARS                    # SURVEY 8(d) reference-algorithm flop-equivalents
 
 
+COMPACT_LIMIT = 4096           # bytes: the round driver keeps the last 8 KB of stdout; round 5's 21.9 KB line was cut and parsed as null
+
+
+def _r(x, nd=6):
+    """numbers rounded to nd significant digits (the full-precision values are in the detail file)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (nd, float(x)))
+    except (TypeError, ValueError):
+        return None
+
+
+def _pick(d, keys, nd=6):
+    return {k: _r(d.get(k), nd) for k in keys if d is not None and k in d} if d else None
+
+
+def compact_line(out, detail_path=None):
+    """The ONE stdout line of the contract, built from the full result dict `out` (which goes to the detail file and stderr): contract fields,
+    `roofline`, `cpu_baseline`, the agreement column, the mid-lap figures and C4 at 1 / 64 trials -- numbers only, no prose.  Kept under
+    COMPACT_LIMIT bytes whatever flags are on (tests/test_bench_line.py builds it from a canned dict; the GPU test asserts it on the real line)."""
+    rf = out.get("roofline") or {}
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c["value"], c["ms_per_step"] = _r(c["value"], 9), _r(c["ms_per_step"], 7)
+    c["mpc_steps_per_s"] = _r(out.get("mpc_steps_per_s"), 7)
+    cfg = out.get("config") or {}
+    c["config"] = {"workload": str(cfg.get("workload", ""))[:160], **{k: cfg.get(k) for k in ("total_trials", "trials_per_gpu", "rollouts_per_step", "parallelism") if k in cfg}}
+    rep = out.get("repeats")
+    if rep:
+        c["repeats"] = {"n": rep.get("n"), "ms_median": _r(rep["ms_per_step"]["median"]), "ms_min": _r(rep["ms_per_step"]["min"]), "ms_max": _r(rep["ms_per_step"]["max"])}
+    c["roofline"] = {"bound": rf.get("bound"), "limiter": rf.get("limiter"), "kernel": rf.get("kernel"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                     "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic")),
+                     **{k: _r(rf.get(k)) for k in ("avg_launch_us", "launches", "rollouts_per_launch", "alg_bytes_per_rollout", "frac_default_schedule", "step_frac",
+                                                   "valu_busy_frac", "kernel_traffic_frac", "fp64_executed_frac")},
+                     "one_stream_ms_per_step": _r((rf.get("one_stream") or {}).get("ms_per_step")),
+                     "issue_frac_of_attainable": _r((rf.get("issue_rate") or {}).get("frac_of_attainable")),
+                     "pmc": "fresh" if "matches" in str(rf.get("pmc_source")) else ("stale" if "STALE" in str(rf.get("pmc_source")) else "none")}
+    kms = out.get("kernel_ms_per_step")
+    if kms:
+        c["kernel_ms_per_step_one_stream"] = {k: _r(v, 4) for k, v in kms.items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "value_1thread", "mpc_steps_per_s")), "sample": str(cb.get("sample", ""))[:120]}
+    ag = out.get("max_rel_err_vs_cpu")
+    if ag:
+        c["max_rel_err_vs_cpu"] = _pick(ag, ("control", "cost", "iters_equal", "steps", "costs_off_by_more_than_1e-5"), 3)
+    ml = out.get("midlap_states")
+    if ml:
+        am = ml.get("max_rel_err_vs_cpu") or {}
+        c["midlap"] = {"closed_loop_ms": _r(ml["closed_loop"]["ms_per_step"]), "closed_loop_value": _r(ml["closed_loop"]["value"]),
+                       "frozen_ms": _r(ml["frozen_at_step_100"]["ms_per_step"]), "frozen_rollout_launch_us": _r(ml["frozen_at_step_100"].get("rollout_avg_launch_us")),
+                       "control_err": _r(am.get("control"), 3), "oracle_self_sensitivity": _r(am.get("oracle_vs_itself_control"), 3),
+                       "cost_err": _r(am.get("cost_all_rollouts"), 3), "iters_equal": am.get("iters_equal")}
+    rows = out.get("configs") or []
+    if rows:
+        c["configs"] = [{"c": r["config"][:2], "trials": r["trials"], "ms": _r(r["ms_per_step"], 4), "rps": _r(r["rollouts_per_s"], 4),
+                         **({"sync_ms": _r(r["abi_sync_ms_per_step"], 4)} if r.get("abi_sync_ms_per_step") else {}),
+                         **({"err": _r(max(r["max_rel_err_vs_cpu"]["control"], r["max_rel_err_vs_cpu"]["cost"]), 2)} if r.get("max_rel_err_vs_cpu") else {}),
+                         **({"cpu_rps": _r(r["cpu_one_trial"]["rollouts_per_s"], 3)} if r.get("cpu_one_trial") else {})} for r in rows]
+        c["configs_keys"] = "ms=ms per MPC step, rps=rollouts/s, sync_ms=one-trial pol(env) via the C ABI, err=max rel err vs cpu (control, cost), cpu_rps=oracle one trial"
+        c4 = [next(r for r in rows if r["config"].startswith("C4") and r["trials"] == t) for t in (1, 64) if any(r["config"].startswith("C4") and r["trials"] == t for r in rows)]
+        c["c4"] = [{"trials": r["trials"], "ms_per_step": _r(r["ms_per_step"], 5), "rollouts_per_s": _r(r["rollouts_per_s"], 5),
+                    **_pick(r.get("rollout_roofline"), ("kernel", "avg_launch_us", "rollouts_per_launch", "alg_bytes_per_rollout", "frac"), 7)} for r in c4]
+    c["summary_gather_path"] = out.get("summary_gather")
+    c["rccl_ranks_seen"] = out.get("rccl_ranks_seen")
+    st = out.get("strong_scaling")
+    if st:
+        c["strong_scaling"] = _pick(st, ("total_trials", "trials_per_gpu", "value", "ms_per_step", "one_gpu_ms_per_step", "speedup_vs_one_gpu", "efficiency_vs_one_gpu"))
+    if detail_path:
+        c["detail"] = detail_path
+    line = json.dumps(c, ensure_ascii=False, separators=(",", ":"))
+    # belt and braces: whatever a future field adds, the line the driver parses stays short -- drop the optional blocks, widest first
+    for k in ("configs", "configs_keys", "kernel_ms_per_step_one_stream", "repeats", "strong_scaling", "midlap", "c4"):
+        if len(line.encode()) <= COMPACT_LIMIT:
+            break
+        c.pop(k, None)
+        line = json.dumps(c, ensure_ascii=False, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """Full record -> gpurun_out/bench_detail_latest.json (merged back by gpurun; copied to profiles/ per round) and stderr; compact line -> stdout, last."""
+    rel = os.path.join("gpurun_out", "bench_detail_latest.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(out, f, ensure_ascii=False, indent=1)
+    except OSError:
+        rel = None
+    sys.stderr.write("BENCH_DETAIL " + json.dumps(out, ensure_ascii=False) + "\n")
+    sys.stderr.flush()
+    print(compact_line(out, rel))
+    sys.stdout.flush()
+
+
 def _oracle_policy(policy, cars, Kc, Nc, nthreads, **kw):
     import numpy as np
     from oracle import oracle as O
@@ -164,13 +259,14 @@ def cpu_baseline(seconds_target=12.0, check_device=None):
     container make the oracle slower, and the fastest setting is the fair baseline."""
     ncpu = os.cpu_count() or 1
     Z0 = _oracle_noise(CARS, K, N_AIS, 0)
-    best_t, best_n, t_cal = None, 1, 0.0
+    best_t, best_n, t_cal, table = None, 1, 0.0, {}
     for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)}):
         env, pol = _oracle_policy("μΣaismppi", CARS, K, N_AIS, nt)
         t0 = time.perf_counter()
         pol(env, Z0)
         dt = time.perf_counter() - t0
         t_cal += dt
+        table[str(nt)] = round(N_AIS * K / dt)          # rollouts/s of one MPC step at this thread count: the calibration, printed so the choice is reproducible
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
         if dt > 4 * best_t:
@@ -185,7 +281,7 @@ def cpu_baseline(seconds_target=12.0, check_device=None):
             "value_1thread": N_AIS * K / t_one, "sample_1thread": "1 MPC step of 1 trial (%d rollouts), 1 thread, %.1f s" % (N_AIS * K, t_one),
             "sample": "%d MPC step(s) of 1 trial, same config (%d rollouts), C oracle + OpenMP over k, %.1f s (+%.1f s calibrating the thread count; host reports %d CPUs)"
                       % (r["steps"], r["steps"] * N_AIS * K, r["seconds"], t_cal, ncpu),
-            "mpc_steps_per_s": r["mpc_steps_per_s"], "max_rel_err_vs_cpu": r.get("max_rel_err_vs_cpu")}
+            "mpc_steps_per_s": r["mpc_steps_per_s"], "thread_calibration_rollouts_per_s": table, "max_rel_err_vs_cpu": r.get("max_rel_err_vs_cpu")}
 
 
 def cpu_configs(nthreads, check_device=None):
@@ -301,8 +397,27 @@ def measure_config(name, policy, cars, Kc, Nc, trials, steps, device, closed_loo
             eng.bench_policy_steps(tsteps)
         tm = eng.timing_read()
         eng.timing_enable(False)
+        # the rollout kernel with the chip to itself (ONE stream, HIP events around the rollout launches only): the contract's roofline formula for
+        # this config -- alg_bytes x rollouts per launch / average launch time / 8 TB/s -- next to profiles/r06_c4_b64_kernel_stats.csv
+        eng.set_overlap(1)
+        if closed_loop:
+            eng.reset(); eng.set_U(np.zeros((trials, cs))); eng.seed(20240000)
+            eng.timing_enable(2); eng.timing_reset()
+            rl_iso = float(eng.run_trials(num_steps=min(steps, 4) - 1, laps=2)[:, 14].sum())      # executed rollouts of exactly this call
+        else:
+            eng.bench_policy_steps(2)
+            eng.timing_enable(2); eng.timing_reset()
+            _, rl_iso = eng.bench_policy_steps(min(steps, 5))
+        tm_iso = eng.timing_read()
+        eng.timing_enable(False)
     finally:
         eng.close()
+    iso = None
+    if tm_iso.get("rollout", (0, 0))[1]:
+        i_ms, i_n = tm_iso["rollout"]
+        per_l = rl_iso / i_n
+        iso = {"kernel": ("k_rollout_cars<%d,...>" % cars) if cars > 1 else "k_rollout_car<1,...>", "avg_launch_us": i_ms / i_n * 1e3, "launches": i_n, "rollouts_per_launch": per_l,
+               "alg_bytes_per_rollout": alg_bytes(policy, cs), "frac": per_l * alg_bytes(policy, cs) / (i_ms / i_n * 1e-3) / (HBM_PEAK_GBS * 1e9), "schedule": "one stream"}
     per_step = {k: v[0] / tsteps for k, v in tm.items() if v[1]}
     dom = max(per_step, key=per_step.get)
     overlap = sum(per_step.values()) / (ms / steps)
@@ -310,7 +425,7 @@ def measure_config(name, policy, cars, Kc, Nc, trials, steps, device, closed_loo
     ba = alg_bytes(policy, cs)
     # the reference's own call pattern (one trial, synchronous pol(env) per MPC step through the C ABI), next to the resident figure
     sync = measure_sync_calls(policy, cars, Kc, Nc, 60 if Kc * Nc * cars < 20000 else 12, device, frozen=not closed_loop, **kw) if trials == 1 else {}
-    return {**sync, "config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
+    return {**sync, "rollout_roofline": iso, "config": name, "trials": trials, "steps": steps, "ms_per_step": ms / steps, "rollouts_per_s": rps, "mpc_steps_per_s": trials * steps / (ms * 1e-3),
             "loop": "closed loop (mpopis_run_trials)" if closed_loop else "policy steps (mpopis_bench_policy_steps)",
             "kernel_ms_per_step": per_step, "dominant": {"class": dom, "avg_launch_us": tm[dom][0] / tm[dom][1] * 1e3, "share_of_kernel_time": per_step[dom] / sum(per_step.values())},
             "kernel_time_over_step_time": overlap,
@@ -376,6 +491,10 @@ def main():
     ap.add_argument("--multi-stream", action="store_true", help="(accepted for old command lines; the part-chain schedule is the engine's default now and the one-stream pass always runs)")
     # development aids for exercising the N > 1 control flow on a 1-GPU box (never used by the driver): all ranks on cuda:0 over gloo.
     # RCCL refuses two ranks on one device, so this also exercises the fall-back from the ABI gather to torch.distributed's.
+    ap.add_argument("--allow-gather-fallback", action="store_true",
+                    help="N > 1: if RCCL cannot be bound behind the C ABI (mpopis_comm_init), degrade to torch.distributed's gather and say so in the line. "
+                         "Default for the nccl backend is STRICT: the run fails instead, so that a scaling number always exercised csrc/engine_comm.hip")
+    ap.add_argument("--require-rccl", action="store_true", help="force the strict behaviour also with the gloo development backend (tests)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--same-gpu", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): rank 0 prints {\"launch_check\": world}; used by the CPU test of the self-launch")
@@ -477,8 +596,27 @@ def main():
             return None
         return res.get("err", "timeout" if th.is_alive() else "failed on another rank")
 
+    rccl_ranks_seen = None
+    strict_rccl = world > 1 and (args.backend == "nccl" or args.require_rccl) and not args.allow_gather_fallback
+
+    def rccl_failed(why):
+        # every rank reaches this together (the verdicts above are all_reduce'd), so the group can be torn down cleanly
+        if rank == 0:
+            sys.stderr.write("bench.py: RCCL behind the C ABI is required for --gpus %d and could not be used: %s\n"
+                             "          (pass --allow-gather-fallback to degrade to torch.distributed's gather and label the line)\n" % (world, why))
+        dist.destroy_process_group()
+        sys.exit(3)
+
     if dist is not None:
         err = abi_comm_init(eng)
+        if err is None:
+            rccl_ranks_seen = eng.comm_count()              # ncclCommCount of the communicator the gather runs on
+            seen = torch.tensor([rccl_ranks_seen], device=cdev)
+            dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+            if int(seen.item()) != world:
+                err = "ncclCommCount reports %d ranks, expected %d" % (int(seen.item()), world)
+        if err is not None and strict_rccl:
+            rccl_failed(err)
         gather_path = "mpopis_gather_summary (RCCL behind the C ABI)" if err is None else "torch.distributed gather (ABI path: %s)" % err
 
     def summary_gather(e):
@@ -582,8 +720,12 @@ def main():
         eng_s = Engine("car", CARS, "μΣaismppi", K, H, batch=Bs, lam=LAM, alpha=1.0, ais_its=N_AIS, lam_ais=LAM_AIS,
                        cov=np.tile([0.0625, 0.1], CARS), seed=20240000, device=local_rank)
         eng_s.seed_slots([20240000 + 1 + rank + i * world for i in range(Bs)])       # trial k -> rank (k-1) mod N
-        if gather_path.startswith("mpopis") and abi_comm_init(eng_s) is not None:
-            gather_path = "torch.distributed gather (ABI path failed for the second communicator)"
+        if gather_path.startswith("mpopis"):
+            err_s = abi_comm_init(eng_s)
+            if err_s is not None:
+                if strict_rccl:
+                    rccl_failed("second communicator (strong-scaling handle): " + err_s)
+                gather_path = "torch.distributed gather (ABI path failed for the second communicator)"
         eng_s.bench_policy_steps(args.warmup)
         sync()
         t0s = time.perf_counter()
@@ -651,10 +793,10 @@ def main():
             "repeats": {"n": len(samples), "what": "the timed region repeated back to back (first sample = the contract's timed region = `value`)",
                         "ms_per_step": {"median": med / args.steps * 1e3, "min": srt[0] / args.steps * 1e3, "max": srt[-1] / args.steps * 1e3},
                         "value": {"median": total_rollouts / med, "max": total_rollouts / srt[0], "min": total_rollouts / srt[-1]}},
-            "roofline": {"bound": "fp64_valu", "contract_bound": "hbm", "kernel": "k_rollout_car<1, 4, false, true>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "fp64_valu_issue", "kernel": "k_rollout_car<1, 4, false, true>", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "pmc_source": pmc_state,
                          "kernel_isolation": "one-stream pass of the same workload (mpopis_set_overlap(h, 1); = MPOPIS_NSPLIT=1), right after the timed region, same process: "
-                                             "%.3f ms per step there; profiles/r05_bench_kernel_stats.csv is taken the same way" % (ms_one / args.steps),
+                                             "%.3f ms per step there; profiles/r06_bench_kernel_stats.csv is taken the same way" % (ms_one / args.steps),
                          "frac_default_schedule": d_per_launch * BYTES_PER_ROLLOUT / d_avg_s / 1e9 / HBM_PEAK_GBS,
                          "default_schedule": {"parts": parts, "rollout_avg_launch_us": d_avg_s * 1e6, "rollout_launches": d_n, "rollouts_per_launch": d_per_launch,
                                               "what": "the schedule of the timed region (`value`), measured again with HIP events right after it: the engine's default for this shape = %d skewed part-chains on their own HIP streams; "
@@ -667,7 +809,7 @@ def main():
                          "fp64_executed_frac": (flops_exec * per_launch / r_avg_s / (FP64_PEAK_TFLOPS * 1e12)) if flops_exec else None,
                          "avg_launch_us": r_avg_s * 1e6, "launches": r_n, "rollouts_per_launch": per_launch, "alg_bytes_per_rollout": BYTES_PER_ROLLOUT,
                          "schedule": "achieved / frac / avg_launch_us: one-stream pass, %d launch per AIS iteration, all %d trials in one launch, nothing else on the GPU while it runs" % (max(1, round(r_n / (3 * args.steps * N_AIS))), B),
-                         "bound_note": "achieved / peak / frac are the HBM figure the bench contract prescribes (contract_bound); `bound` names the resource that actually limits the kernel; valu_busy_frac from the PMC pass in profiles/",
+                         "bound_note": "achieved / peak / frac are the HBM figure the bench contract prescribes (`bound`); `limiter` names the resource that actually limits the kernel; valu_busy_frac from the PMC pass in profiles/",
                          "valu_busy_frac": valu_busy,
                          # what the FP64 VALU sustains: tools/mfma_rate.hip -- bare independent v_fma_f64 streams issue one wave-instruction per
                          # 5.0 cycles per SIMD at 4 waves per SIMD (the kernel's occupancy: 128 VGPRs), 4.6 at 8, 8.8 from a lone wave; the
@@ -683,7 +825,7 @@ def main():
                          "note": "fp64_reference_* prices SURVEY 8(d)'s 3.5e5 flop-equivalents of the REFERENCE formulation per rollout; the kernel executes ~4x fewer (transcendental-free sub-step), so this can exceed 1"},
             "kernel_ms_per_step": {k: v[0] / max(1, min(args.steps, 5)) for k, v in tm_all.items() if v[1]},
             "kernel_ms_per_step_schedule": "one-stream pass (per-class times add up to its step time; in the default schedule the classes of different part-chains overlap)",
-            "summary_gather": gather_path,
+            "summary_gather": gather_path, "rccl_ranks_seen": rccl_ranks_seen, "rccl_required": bool(strict_rccl),
             "midlap_states": midlap,
         }
         if strong is not None:
@@ -696,12 +838,14 @@ def main():
             if "configs" in out and not args.quick_configs:
                 cpu = cpu_configs(out["cpu_baseline"]["cores"], check_device=local_rank)      # CPU rows of the same table, one trial each
                 for c in out["configs"]:
+                    if c["trials"] != 1:
+                        continue                      # the agreement check and the CPU row are ONE-trial measurements: they go on the one-trial row only
                     row = dict(cpu[c["config"][:2]])
                     c["max_rel_err_vs_cpu"] = row.pop("max_rel_err_vs_cpu", None)
                     c["cpu_one_trial"] = row
         if world > 1:
             out["n1_only"] = "cpu_baseline, max_rel_err_vs_cpu and the configs block (C2/C3/C4, abi_sync_ms_per_step) are measured at N = 1 only (one GPU, rank 0's host cores)"
-        print(json.dumps(out, ensure_ascii=False))
+        emit(out)
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

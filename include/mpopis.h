@@ -42,8 +42,9 @@ extern "C" {
  * 3: + mpopis_policy_call (control = pol(env) with a single host wait).  Nothing removed or changed in meaning.
  * 4: no new entry point; the execution knob mpopis_set_overlap changed: the default (on <= 0) is now the engine's own choice of schedule for the
  *    handle's shape instead of one stream, and on = 1 means "one stream" instead of "two halves".  Results never depended on the knob (bit-identical
- *    per slot in every schedule), so a version-3 caller sees the same numbers, sooner. */
-#define MPOPIS_ABI_VERSION 4
+ *    per slot in every schedule), so a version-3 caller sees the same numbers, sooner.
+ * 5: + mpopis_comm_count (the number of ranks RCCL itself reports for the handle's communicator).  Nothing removed or changed in meaning. */
+#define MPOPIS_ABI_VERSION 5
 
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };
 
@@ -211,12 +212,16 @@ int  mpopis_run_trials(mpopis_handle *h, int32_t num_steps, int32_t laps, double
  *   mpopis_gather_summary : every rank passes its n_local records (rows of MPOPIS_RECORD_LEN doubles); n_max = the largest
  *                           n_local over ranks (ceil(num_trials / world)).  Rank 0 receives out[world][n_max][RECORD_LEN]
  *                           and counts[world] (rows valid per rank); other ranks may pass NULL for both.
+ *   mpopis_comm_count     : *ranks = what ncclCommCount reports for the handle's communicator, 0 when no RCCL communicator is bound
+ *                           (lets a launcher prove the gather really spans its N ranks; replaces nothing in the reference, whose
+ *                           trial loop is serial: src/examples/car_example.jl:170)
  * librccl is bound with dlopen at the first comm call; single-GPU users never load it. */
 #define MPOPIS_COMM_ID_BYTES 128
 int  mpopis_comm_unique_id(char *id128);
 int  mpopis_comm_init(mpopis_handle *h, const char *id128, int32_t rank, int32_t world);
 int  mpopis_gather_summary(mpopis_handle *h, const double *records, int32_t n_local, int32_t n_max,
                            double *out, int32_t *counts);
+int  mpopis_comm_count(mpopis_handle *h, int32_t *ranks);
 int  mpopis_comm_destroy(mpopis_handle *h);
 
 /* Execution knob.  A handle can split its batch into parts that run as independent chains on their own HIP streams, so that

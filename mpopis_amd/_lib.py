@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "mpopis_seed", "mpopis_seed_slots", "mpopis_get_Sigma", "mpopis_rollout_costs", "mpopis_policy_step", "mpopis_env_step",
     "mpopis_env_query", "mpopis_get_trajectories", "mpopis_set_state_noise", "mpopis_run_trials", "mpopis_timing_enable", "mpopis_timing_read",
     "mpopis_timing_reset", "mpopis_bench_policy_steps",
-    "mpopis_policy_call", "mpopis_set_overlap", "mpopis_comm_unique_id", "mpopis_comm_init", "mpopis_gather_summary", "mpopis_comm_destroy",
+    "mpopis_policy_call", "mpopis_set_overlap", "mpopis_comm_unique_id", "mpopis_comm_init", "mpopis_gather_summary", "mpopis_comm_destroy", "mpopis_comm_count",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
         L.mpopis_comm_init.argtypes = [H, C.c_char_p, C.c_int32, C.c_int32]
         L.mpopis_gather_summary.argtypes = [H, _dp, C.c_int32, C.c_int32, _dp, _ip]
         L.mpopis_comm_destroy.argtypes = [H]
+        L.mpopis_comm_count.argtypes = [H, _ip]
         _lib = L
     return _lib
 

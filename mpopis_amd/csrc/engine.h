@@ -213,7 +213,9 @@ void launch_ce_cov_small(const double* E, int32_t* order, double* mu, double* S,
 // kernels_select.hip
 void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_elite, int* active, hipStream_t s,
                      double* skey = nullptr, int* done = nullptr);   // + elite early break; skey [B][K] / done [B] (zeroed): workspace of the chip-wide rank sort
-void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws = nullptr);
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws = nullptr,
+                        int32_t* stack_ws = nullptr /* B x 2K ints, needed when K > alias_lds_max_K() */);
+int alias_lds_max_K();
 void launch_alias_sample(const double* accept, const int32_t* alias, const int32_t* di, size_t di_stride, const double* du,
                          int32_t* out, int32_t* log, size_t log_stride, int B, int K, const int* active, hipStream_t s);
 

@@ -87,7 +87,7 @@ int mpopis_handle::ais_update(int n, bool injected) {
         launch_weights(d_cost, d_w, B, K, cfg.lambda_ais, d_active, d_status, stream);
         time_end();
         time_begin(5);
-        launch_alias_build(d_w, d_accept, d_alias, B, K, d_active, stream, d_alias_need);                   // Categorical(ws) -> AliasTable
+        launch_alias_build(d_w, d_accept, d_alias, B, K, d_active, stream, d_alias_need, d_alias_stack);                   // Categorical(ws) -> AliasTable
         const int32_t* di; const double* du; size_t stride;
         if (injected) { di = d_resi_in + (size_t)(n - 1) * K; du = d_resu_in + (size_t)(n - 1) * K; stride = (size_t)(N - 1) * K; }
         else {

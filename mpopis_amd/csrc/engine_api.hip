@@ -240,6 +240,7 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
     rc |= dalloc(h, &h->d_seeds, B); rc |= dalloc(h, &h->d_rng_tab, mpopis::kRngTabDoubles);      // philox.h
     rc |= dalloc(h, &h->d_order, (size_t)B * K); rc |= dalloc(h, &h->d_resi, (size_t)B * K); rc |= dalloc(h, &h->d_resu, (size_t)B * K);
     rc |= dalloc(h, &h->d_accept, (size_t)B * K); rc |= dalloc(h, &h->d_alias, (size_t)B * K); rc |= dalloc(h, &h->d_alias_need, B);
+    if (cfg->policy == MPOPIS_POL_PMCMPPI && K > alias_lds_max_K()) rc |= dalloc(h, &h->d_alias_stack, (size_t)B * 2 * K);      // the global-workspace alias construction
     rc |= dalloc(h, &h->d_residx_log, (size_t)B * std::max(1, h->N - 1) * K);
     h->ksplit = std::max(1, std::min(std::min(32, K / 128), std::max(1, 512 / B)));   // ~2-4 workgroups per CU in the scatter kernel
     if (const char* e = getenv("MPOPIS_KSPLIT")) h->ksplit = std::max(1, std::min(32, atoi(e)));
@@ -278,8 +279,8 @@ int mpopis_create(const mpopis_config* cfg, mpopis_handle** out) {
         if (hipMemcpy(h->d_cma_ws, h->cma_ws_host.data(), sizeof(double) * K, hipMemcpyHostToDevice) != hipSuccess) { g_create_error = "upload failed"; mpopis_destroy(h); return MPOPIS_ERR_HIP; }
     }
     if (cfg->policy == MPOPIS_POL_CEMPPI) h->m_elite = (int)nearbyint(K * (1 - cfg->elite_threshold));   // :437
-    if ((cfg->policy == MPOPIS_POL_CEMPPI || cfg->policy == MPOPIS_POL_CMAMPPI) && K > 8192) { g_create_error = "cemppi/cmamppi: K <= 8192 supported"; mpopis_destroy(h); return MPOPIS_ERR_ARG; }
-    if (cfg->policy == MPOPIS_POL_PMCMPPI && K > 7168) { g_create_error = "pmcmppi: K <= 7168 supported"; mpopis_destroy(h); return MPOPIS_ERR_ARG; }
+    // (no upper limit on K: beyond K = 8192 the sort is the chunked chip-wide rank sort, beyond 7168 the alias table is built on global arrays --
+    // the reference's sortperm / Categorical take any K, :455, :804)
     *out = h;
     return MPOPIS_OK;
 }
@@ -774,7 +775,7 @@ void mpopis_handle::shift_slots(ptrdiff_t db) {
     mv(d_wn, cs); mv(d_mu, cs); mv(d_gvec, cs); mv(d_control, as); mv(d_reward, 1); mv(d_traj, (ptrdiff_t)K * T * ss);
     mv(d_status, 1); mv(d_active, 1); mv(d_iters, 1); mv(d_iters_acc, 1); mv(d_seeds, 1);
     mv(d_order, K); mv(d_resi, K); mv(d_alias, K); mv(d_residx_log, (ptrdiff_t)std::max(1, N - 1) * K); mv(d_resi_in, (ptrdiff_t)(N - 1) * K);
-    mv(d_resu, K); mv(d_accept, K); mv(d_alias_need, 1); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
+    mv(d_resu, K); mv(d_accept, K); mv(d_alias_need, 1); mv(d_alias_stack, 2 * (ptrdiff_t)K); mv(d_resu_in, (ptrdiff_t)(N - 1) * K);
     mv(d_part, (ptrdiff_t)(wcov_mfma_workspace_doubles(1, cs, ksplit)));
     mv(d_cma_scal, 8); mv(d_cma_vec, 3 * (ptrdiff_t)cs); mv(d_sig2, 1);
     mv(d_lanV, (ptrdiff_t)invsqrt_workspace_doubles(1, cs, lan_regions)); mv(d_lan_x, (ptrdiff_t)invsqrt_coop_words(1, cs)); mv(d_Cdw, cs); mv(d_fro_part, (cs + 15) / 16); mv(d_tri_dinv, (ptrdiff_t)trtri_dinv_doubles(1, cs)); mv(d_fro, 1); mv(d_lan_m, 1); mv(d_lan_prep, (ptrdiff_t)lanczos_prep_doubles(1)); mv(d_tri_cnt, 2);

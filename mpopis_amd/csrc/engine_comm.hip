@@ -27,6 +27,7 @@ struct RcclApi {
     int (*GetUniqueId)(RcclUniqueId*) = nullptr;
     int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int) = nullptr;
     int (*CommDestroy)(RcclComm) = nullptr;
+    int (*CommCount)(const RcclComm, int*) = nullptr;
     int (*Gather)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;       // RCCL extension
     int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -46,6 +47,7 @@ bool load_rccl() {
     a.GetUniqueId = (int (*)(RcclUniqueId*))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (int (*)(RcclComm*, int, RcclUniqueId, int))dlsym(lib, "ncclCommInitRank");
     a.CommDestroy = (int (*)(RcclComm))dlsym(lib, "ncclCommDestroy");
+    a.CommCount = (int (*)(const RcclComm, int*))dlsym(lib, "ncclCommCount");
     a.Gather = (int (*)(const void*, void*, size_t, int, int, RcclComm, hipStream_t))dlsym(lib, "ncclGather");
     a.AllGather = (int (*)(const void*, void*, size_t, int, RcclComm, hipStream_t))dlsym(lib, "ncclAllGather");
     a.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
@@ -88,6 +90,21 @@ int mpopis_comm_init(mpopis_handle* h, const char* id128, int32_t rank, int32_t 
     const int rc = g_rccl.CommInitRank(&c, world, id, rank);
     if (rc != kRcclSuccess) { h->err = rccl_err("ncclCommInitRank", rc); h->comm_world = 1; h->comm_rank = 0; return MPOPIS_ERR_HIP; }
     h->comm = c;
+    return MPOPIS_OK;
+}
+
+// How many ranks the handle's communicator really spans, asked of RCCL itself (ncclCommCount): 0 = no RCCL communicator is bound
+// (world == 1 without an id, or mpopis_comm_init never ran / failed).  A launcher uses it to tell "the gather went over RCCL with N ranks"
+// from "it silently ran some other way".
+int mpopis_comm_count(mpopis_handle* h, int32_t* ranks) {
+    if (!h || !ranks) { if (h) h->err = "mpopis_comm_count: null argument"; return MPOPIS_ERR_ARG; }
+    *ranks = 0;
+    if (!h->comm) return MPOPIS_OK;
+    if (!g_rccl.CommCount) { h->err = "librccl lacks ncclCommCount"; return MPOPIS_ERR_HIP; }
+    int n = 0;
+    const int rc = g_rccl.CommCount((RcclComm)h->comm, &n);
+    if (rc != kRcclSuccess) { h->err = rccl_err("ncclCommCount", rc); return MPOPIS_ERR_HIP; }
+    *ranks = (int32_t)n;
     return MPOPIS_OK;
 }
 

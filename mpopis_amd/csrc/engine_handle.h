@@ -61,6 +61,7 @@ struct mpopis_handle {
     int coop_share = 1;                                                                    // multi-stream schedule: that many cluster launches may be in flight at once
     mpopis::CoopCtx potrf_coop() { mpopis::CoopCtx c; if (!coop_disabled) { c.flags = d_coop_flags; c.epoch = &coop_epoch; c.redo = d_potrf_redo; c.timeouts = d_coop_timeouts; c.share = coop_share; } return c; }
     mpopis::CoopCtx lan_coop() { mpopis::CoopCtx c; if (!coop_disabled) { c.flags = d_lan_x; c.epoch = &coop_epoch; c.redo = d_lan_redo; c.timeouts = d_coop_timeouts; c.share = coop_share; } return c; }
+    int32_t* d_alias_stack = nullptr;                                                      // :pmcmppi with K beyond the LDS-resident alias construction: the two stacks (B x 2K ints)
     int* d_alias_need = nullptr;                                                           // :pmcmppi: slots whose alias table the parallel construction could not certify
     int* d_lan_m = nullptr;                                                                // Lanczos steps taken per slot (diagnostic)
     unsigned long long* d_tri_cnt = nullptr;                                               // [B][2]: arrival counter of a slot's trace workgroups (the last one prepares the Lanczos run) and their ||Σ||_inf; zero between launches

@@ -259,7 +259,9 @@ __global__ void __launch_bounds__(128 * W) k_trtri_fro_pair(const double* __rest
     // drawn -- no device-scope fence: on this part a release at agent scope writes the whole L2 back (tens of us once the rollouts' E lines are dirty in it)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) sh_last = (atomicAdd(&sy[0], 1ull) == (unsigned long long)gridDim.x - 1) ? 1 : 0;
+    // (the ticket is an ACQUIRE at agent scope -- a buffer invalidate here, no L2 write-back -- so that the last workgroup's reads of part[] / sy[1] happen-after
+    // every other workgroup's ticket under the HIP memory model; the release side is the store-acknowledge wait above: gfx9 family only, see kernels_select.hip)
+    if (tid == 0) sh_last = (__hip_atomic_fetch_add(&sy[0], 1ull, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!sh_last || wv != 0) return;
     const double Mhi = __longlong_as_double((long long)__hip_atomic_load(&sy[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -529,6 +531,9 @@ __device__ __forceinline__ int lanczos_run(const int b, const int g, const doubl
             const double eb = bt * wave_sum(q_wres * fabs(gcur));
             conv = (eb <= kLanTol * (1.0 / sqrt(Mhi))) || (bt <= 1e-14 * Mhi) || (m >= mcap);      // identical in every wave (same node table, same recurrences): no flag, no barrier
         }
+        // LOCKSTEP ASSUMPTION (documented because a divergence would deadlock the next barrier): a_j and bt are sums of the SAME LDS partials (red2) in the SAME
+        // order in every thread, q_* are per-lane copies of one table, so `conv` is bit-identical in every wave.  alpha[j] / beta[j] were written by tid 0 --
+        // a lane of wave 0 -- and are read after the loop by wave 0 only: same-wave program order, no barrier needed on the break path.
         LPROF(j, 4);
         if (conv) break;
         const double rbt = fast_rcp(bt);

@@ -2,8 +2,9 @@
 //   order = sortperm(trajectory_cost)                       src/mppi_mpopi_policies.jl:455,563
 //   early break: maximum(abs.(diff(elite_traj_cost))) < 10e-3   :458-461,:566-569
 //   Categorical(ws) -> AliasTable (StatsBase.make_alias_table!) + rand(rng, ., K)   :804-805
-// One workgroup per trial slot; K <= 8192 (sort) / K <= 7168 (alias) live entirely in LDS.
+// One workgroup per trial slot while K <= 8192 (sort) / K <= 7168 (alias) lets the slot live entirely in LDS; chip-wide / global-workspace forms beyond.
 #include "engine.h"
+#include <type_traits>
 
 namespace mpopis {
 
@@ -156,6 +157,41 @@ __global__ void __launch_bounds__(256) k_sortperm_rank(const double* __restrict_
     elite_break_tail(sc, m_elite, active, b);
 }
 
+
+// ---- elite early break (:458-461 / :566-569) by the LAST workgroup of the slot (chip-wide rank sorts) ----------------------------------------
+// Hand-off of the elite keys: the keys are agent-scope stores (written through to where every XCD's agent-scope loads find them); a workgroup
+// draws its ticket once its own stores are acknowledged (s_waitcnt vmcnt(0): on gfx9 -- gfx950 included -- stores count on vmcnt, there is no vscnt).
+// The ticket itself is an ACQUIRE at agent scope (a buffer invalidate on this part, no L2 write-back), so that under the HIP memory model the last
+// workgroup's reads of skey happen-after every other workgroup's ticket; the release side stays the explicit store-acknowledge wait instead of a
+// release fence (which writes the whole L2 back: 23 -> 21 us per sort at one C4 slot, and much more beside dirty rollout data).
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the vmcnt-acknowledged hand-off below is written for the gfx9 family (stores counted on vmcnt, agent-scope stores written through)"
+#endif
+__device__ __forceinline__ void elite_break_last_workgroup(double* __restrict__ skey, int* __restrict__ done, int m_elite, int* active, int b, int K,
+                                                           int* sh_last, double* eb) {
+    const int tid = threadIdx.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *sh_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!*sh_last) return;
+    double mx = -INFINITY;
+    for (int q = tid; q + 1 < m_elite; q += 256) {
+        const double a0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double a1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mx = fmax(mx, fabs(a1 - a0));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) eb[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        mx = fmax(fmax(eb[0], eb[1]), fmax(eb[2], eb[3]));
+        if (mx < 10e-3) active[b] = 0;
+        done[b] = 0;                                                          // ready for the next launch (stream order)
+    }
+}
+
 // Large K at a few slots (C4: K = 4096, 1-16 trials): the bitonic network above is one workgroup per slot and ~49 us of pure latency (78 dependent
 // compare-exchange steps) on a chip that is otherwise idle.  Rank sort across the whole chip instead: K^2 independent comparisons.  A workgroup owns
 // kRmE = 16 entries; thread (el, js) counts how many entries of the js-th sixteenth of the slot precede entry el in the (cost, index) order (all K costs
@@ -194,33 +230,58 @@ __global__ void __launch_bounds__(256) k_sortperm_rank_multi(const double* __res
     if (tid < kRmE && e < K) {
         const int rank = sh_rank[el];
         order[(size_t)b * K + rank] = e;
-        if (rank < m_elite) __hip_atomic_store((unsigned long long*)&skey[(size_t)b * K + rank], (unsigned long long)__double_as_longlong(ce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (skey && rank < m_elite) __hip_atomic_store((unsigned long long*)&skey[(size_t)b * K + rank], (unsigned long long)__double_as_longlong(ce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (m_elite < 2 || !active) return;
-    // ---- elite early break (:458-461 / :566-569) by the last workgroup of the slot -------------------------------------------------------------
-    // Hand-off of the elite keys to the last workgroup of the slot: the keys are agent-scope stores (written through to where every XCD's agent-scope
-    // loads find them); a workgroup draws its ticket once its stores are acknowledged (vmcnt).  No release / acquire at agent scope: on this part a
-    // release writes the whole L2 back (23 -> 21 us per sort at one C4 slot, and much more beside dirty rollout data).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) sh_last = (__hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!sh_last) return;
-    double mx = -INFINITY;
-    for (int q = tid; q + 1 < m_elite; q += 256) {
-        const double a0 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const double a1 = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&skey[(size_t)b * K + q + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        mx = fmax(mx, fabs(a1 - a0));
+    if (m_elite < 2 || !active || !skey || !done) return;
+    elite_break_last_workgroup(skey, done, m_elite, active, b, K, &sh_last, eb);
+}
+
+// Any K (the reference's sortperm has no size limit, src/mppi_mpopi_policies.jl:455,563): the chip-wide rank sort with the slot's costs streamed through
+// LDS in chunks of kRbChunk instead of held whole (k_sortperm_rank_multi keeps all K costs of the slot in LDS: K <= 12288; the bitonic kernels K <= 8192).
+// Same counting, same (cost, index) order, same hand-off of the elite keys to the slot's last workgroup.  Work is B K^2 comparisons: the path for
+// K > 8192 only (K = 16384: 2.7e8 per slot).
+constexpr int kRbChunk = 4096;
+__global__ void __launch_bounds__(256) k_sortperm_rank_big(const double* __restrict__ cost, int32_t* __restrict__ order, int K, int m_elite, int* active,
+                                                           double* __restrict__ skey, int* __restrict__ done) {
+    MPOPIS_HI_PRIO();
+    __shared__ __attribute__((aligned(16))) double c_l[kRbChunk];
+    __shared__ int sh_rank[kRmE];
+    __shared__ int sh_last;
+    __shared__ double eb[4];
+    const int b = blockIdx.y;
+    if (active && !active[b]) return;
+    const int tid = threadIdx.x, el = tid & (kRmE - 1), js = tid >> 4;
+    if (tid < kRmE) sh_rank[tid] = 0;
+    const int e = blockIdx.x * kRmE + el;
+    double ce = INFINITY;
+    if (e < K) { const double v = cost[(size_t)b * K + e]; ce = (v != v) ? INFINITY : v; }      // NaN ranks like +inf (see k_sortperm_rank)
+    int cnt = 0;
+    for (int c0 = 0; c0 < K; c0 += kRbChunk) {
+        const int nc = min(kRbChunk, K - c0);
+        __syncthreads();
+        for (int j = tid; j < nc; j += 256) { const double v = cost[(size_t)b * K + c0 + j]; c_l[j] = (v != v) ? INFINITY : v; }
+        __syncthreads();
+        const int JR = ((nc + 15) / 16 + 3) & ~3, j0 = js * JR, j1 = min(nc, j0 + JR);
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            const double c0v = c_l[j], c1 = c_l[j + 1], c2 = c_l[j + 2], c3 = c_l[j + 3];
+            const int g = c0 + j;
+            cnt += ((c0v < ce) || (c0v == ce && g < e)) + ((c1 < ce) || (c1 == ce && g + 1 < e)) + ((c2 < ce) || (c2 == ce && g + 2 < e)) +
+                   ((c3 < ce) || (c3 == ce && g + 3 < e));
+        }
+        for (; j < j1; ++j) cnt += ((c_l[j] < ce) || (c_l[j] == ce && c0 + j < e));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0) eb[tid >> 6] = mx;
+    cnt += __shfl_xor(cnt, 16, 64);
+    cnt += __shfl_xor(cnt, 32, 64);
+    if ((tid & 63) < kRmE) atomicAdd(&sh_rank[el], cnt);
     __syncthreads();
-    if (tid == 0) {
-        mx = fmax(fmax(eb[0], eb[1]), fmax(eb[2], eb[3]));
-        if (mx < 10e-3) active[b] = 0;
-        done[b] = 0;                                                          // ready for the next launch (stream order)
+    if (tid < kRmE && e < K) {
+        const int rank = sh_rank[el];
+        order[(size_t)b * K + rank] = e;
+        if (skey && rank < m_elite) __hip_atomic_store((unsigned long long*)&skey[(size_t)b * K + rank], (unsigned long long)__double_as_longlong(ce), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (m_elite < 2 || !active || !skey || !done) return;
+    elite_break_last_workgroup(skey, done, m_elite, active, b, K, &sh_last, eb);
 }
 
 // order = sortperm(cost) per slot, and (m_elite >= 2) the elite early-break check on the sorted costs.
@@ -233,6 +294,10 @@ void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_eli
         static std::atomic<unsigned long long> seenm{0};
         ensure_dyn_lds((const void*)k_sortperm_rank_multi, 96 * 1024, seenm);
         hipLaunchKernelGGL(k_sortperm_rank_multi, dim3((K + kRmE - 1) / kRmE, B), dim3(256), (size_t)K * sizeof(double), s, cost, order, K, m_elite, active, skey, done);
+        return;
+    }
+    if (K > 8192) {                                                         // beyond the one-workgroup bitonic network: chunked chip-wide rank sort, any K
+        hipLaunchKernelGGL(k_sortperm_rank_big, dim3((K + kRmE - 1) / kRmE, B), dim3(256), 0, s, cost, order, K, m_elite, active, skey, done);
         return;
     }
     int n = 512;
@@ -249,14 +314,21 @@ void launch_sortperm(const double* cost, int32_t* order, int B, int K, int m_eli
 // StatsBase.make_alias_table!(w, 1.0, a, alias): Vose's construction with LIFO stacks of smalls and
 // larges, executed in the reference's exact operation order (the result must be bit-identical for
 // identical w).  The wave classifies with ballots (keeps index order), then runs the pairing loop (see below).
-__global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
-                                                    int K, const int* active, const int* need) {
+template <bool GLOBAL>
+__global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w, double* accept, int32_t* alias,
+                                                    int K, const int* active, const int* need, int32_t* stack_ws) {
     MPOPIS_HI_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* a = reinterpret_cast<double*>(smem);
-    int32_t* al = reinterpret_cast<int32_t*>(smem + (size_t)K * 8);
-    int32_t* larges = al + K;
-    int32_t* smalls = larges + K;
+    // GLOBAL = false: a / alias / the two stacks live in LDS (K <= kAliasLdsMaxK: 20 bytes per entry).  GLOBAL = true: any K (the reference's Categorical
+    // has no size limit, :804) -- a and alias are built in place in the output arrays, the stacks in a global workspace (2K ints per slot).  ONE wave runs
+    // the kernel, so every access is same-wave program order through this CU's write-through L1; the barriers / fences below order them as they do in LDS.
+    // (volatile only in the global form: there every access is followed by its own wait, which is what orders a lane-0 store before another lane's later load)
+    using DP = std::conditional_t<GLOBAL, volatile double*, double*>;
+    using IP = std::conditional_t<GLOBAL, volatile int32_t*, int32_t*>;
+    DP a = GLOBAL ? (DP)(accept + (size_t)blockIdx.x * K) : reinterpret_cast<DP>(smem);
+    IP al = GLOBAL ? (IP)(alias + (size_t)blockIdx.x * K) : reinterpret_cast<IP>(smem + (size_t)K * 8);
+    IP larges = GLOBAL ? (IP)(stack_ws + (size_t)blockIdx.x * 2 * K) : al + K;
+    IP smalls = larges + K;
     const int b = blockIdx.x;
     if (active && !active[b]) return;
     if (need && !need[b]) return;                               // the parallel construction was certain of every decision
@@ -328,14 +400,14 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
             pend_idx = l; pend_val = a_l;                                                      // pushed on the smalls
         }
         flushS();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int i = lane; i < ks; i += 64) a[smalls[i]] = 1.0;                                // "should be redundant, except for rounding"
         if (pend_idx >= 0 && lane == 0) a[pend_idx] = 1.0;
     }
     __syncthreads();
-    for (int i = lane; i < K; i += 64) { accept[(size_t)b * K + i] = a[i]; alias[(size_t)b * K + i] = al[i]; }
+    if (!GLOBAL) for (int i = lane; i < K; i += 64) { accept[(size_t)b * K + i] = a[i]; alias[(size_t)b * K + i] = al[i]; }
 }
 // ---------------------------------------------------------------------------------------------
 // The same table without the sequential loop.  What the LIFO discipline of make_alias_table! does, in cumulative terms: pop
@@ -352,6 +424,7 @@ __global__ void __launch_bounds__(64) k_alias_build(const double* __restrict__ w
 // sequentially rounded chain: a floating-point deviation of <= 4 K^2 eps (typically 1e-13); all other entries are bit-identical.
 // ---------------------------------------------------------------------------------------------
 constexpr int kAliasParThreads = 1024;
+constexpr int kAliasLdsMaxK = 7168;                                     // 20 bytes of LDS per entry in k_alias_build<false>
 __global__ void __launch_bounds__(kAliasParThreads) k_alias_build_par(const double* __restrict__ w, double* __restrict__ accept, int32_t* __restrict__ alias,
                                                                       int K, const int* active, int* need) {
     MPOPIS_HI_PRIO();
@@ -449,19 +522,24 @@ __global__ void __launch_bounds__(kAliasParThreads) k_alias_build_par(const doub
 
 // need_ws (nullable): B ints of workspace; with it the parallel construction runs first and the sequential kernel only redoes the slots
 // that the parallel one could not certify
-void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws) {
+void launch_alias_build(const double* w, double* accept, int32_t* alias, int B, int K, const int* active, hipStream_t s, int* need_ws, int32_t* stack_ws) {
     const size_t bytes = (size_t)K * (8 + 4 + 4 + 4);
     static std::atomic<unsigned long long> seen{0}, seenp{0};
     static const int env_par = [] { const char* e = getenv("MPOPIS_ALIAS_PAR"); return e ? atoi(e) : 1; }();
+    if (K > kAliasLdsMaxK) {                                    // beyond what LDS holds: the sequential construction on global arrays (stack_ws: B x 2K ints)
+        hipLaunchKernelGGL(k_alias_build<true>, dim3(B), dim3(64), 0, s, w, accept, alias, K, active, (const int*)nullptr, stack_ws);
+        return;
+    }
     const bool par = need_ws && env_par && K <= 8192;
     if (par) {
         ensure_dyn_lds((const void*)k_alias_build_par, 150 * 1024, seenp);
         hipLaunchKernelGGL(k_alias_build_par, dim3(B), dim3(kAliasParThreads), (size_t)K * 12, s, w, accept, alias, K, active, need_ws);
         if (getenv("MPOPIS_ALIAS_DEBUG")) { std::vector<int> nd(B); (void)hipStreamSynchronize(s); (void)hipMemcpy(nd.data(), need_ws, B * 4, hipMemcpyDeviceToHost); fprintf(stderr, "alias need:"); for (int v : nd) fprintf(stderr, " %d", v); fprintf(stderr, "\n"); }
     }
-    ensure_dyn_lds((const void*)k_alias_build, 160 * 1024, seen);
-    hipLaunchKernelGGL(k_alias_build, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active, par ? (const int*)need_ws : (const int*)nullptr);
+    ensure_dyn_lds((const void*)k_alias_build<false>, 160 * 1024, seen);
+    hipLaunchKernelGGL(k_alias_build<false>, dim3(B), dim3(64), bytes, s, w, accept, alias, K, active, par ? (const int*)need_ws : (const int*)nullptr, (int32_t*)nullptr);
 }
+int alias_lds_max_K() { return kAliasLdsMaxK; }
 
 // rand(rng, s::AliasTable): i = rand(1:n); u = rand(); u < accept[i] ? i : alias[i]
 __global__ void __launch_bounds__(256) k_alias_sample(const double* __restrict__ accept, const int32_t* __restrict__ alias,

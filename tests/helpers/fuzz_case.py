@@ -6,6 +6,10 @@ oracle's own trajectory instead).  Round 5: a third of the slots of the policies
 those slots are held to the north star's 1e-5 on the control with up to a quarter of their costs differing."""
 import numpy as np
 
+# every use of the braked-start yardstick (a slot whose control is beyond 1e-5 of the oracle's but within ten times the oracle's distance from its own 1e-13
+# neighbour) is recorded here; the slice test fails when there are more than a handful, so a regression of the general force rules cannot hide behind it
+waivers = []
+
 
 def tag_of(c):
     return "%s cars=%d K=%d T=%d N=%d B=%d split=%d est=%s rng=%s seed=%d" % (c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"], c["split"], c["est"],
@@ -98,12 +102,14 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
                 # orders (tests/test_gpu_standstill.py: 6-14 % of them, by up to 1e-1); what is held there is the north star's bound on the control
                 allow, tol = (max(2, ncars * K // 4), 1e-5) if braked[b] else (max(2, ncars * K // 200), 1e-6)
                 bad = got["iters_run"][b] != r["iters_run"] or nbad > allow or ea > tol or eu > 10 * tol or not idx_ok
-                if bad and braked[b] and got["iters_run"][b] == r["iters_run"]:
+                # (never for the non-adaptive policies: with N = 1 nothing feeds on perturbed weights, the 1e-5 on the control holds as it stands)
+                if bad and braked[b] and got["iters_run"][b] == r["iters_run"] and kind not in ("mppi", "gmppi") and nbad <= allow and idx_ok:
                     # the yardstick: is the engine farther from the oracle than ten times the oracle's distance from its own 1e-13 neighbour?
                     sa, su = oracle_self_distance(b, U_before[b], Z[b], di[b], du[b], r)
                     if ea <= max(tol, 10.0 * sa) and eu <= max(10 * tol, 10.0 * su):
                         bad = False
                         msgs_note = "note %s step %d slot %d: braked start, control %.1e U %.1e within 10x the oracle's self-distance %.1e / %.1e" % (tag, step, b, ea, eu, sa, su)
+                        waivers.append(msgs_note)
                         if len(notes) < 3:
                             notes.append(msgs_note)
                 if bad:

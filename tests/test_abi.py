@@ -26,7 +26,7 @@ def test_header_symbols_exported(L):
 
 
 def test_abi_version(L):
-    assert L.mpopis_abi_version() == 4      # include/mpopis.h "ABI history"
+    assert L.mpopis_abi_version() == 5      # include/mpopis.h "ABI history"
 
 
 def test_null_handle_is_an_argument_error(L):

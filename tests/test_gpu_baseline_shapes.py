@@ -293,6 +293,18 @@ def test_sortperm_sizes_through_cemppi(eng_mod, oracle, track, K):
     run_case(eng_mod, oracle, track, "cemppi", 1, K, 10, 3, steps=1)
 
 
+def test_K_beyond_the_one_workgroup_kernels(eng_mod, oracle, track):
+    """The reference's sortperm (:455, :563) and Categorical (:804) take any K.  Beyond K = 8192 the engine's sort is the chunked chip-wide rank sort
+    (k_sortperm_rank_big: costs streamed through LDS, early break by the slot's last workgroup), beyond K = 7168 the alias table is built by the
+    sequential construction on global arrays (k_alias_build<true>).  K = 16384 (and a ragged 9001) against the oracle: same elite set and early-break
+    decision for :cemppi / :cmamppi, resampling indices bit-exact for :pmcmppi (asserted inside run_case)."""
+    run_case(eng_mod, oracle, track, "cemppi", 1, 16384, 10, 3, B=2, steps=1, sigma_est="ss")
+    run_case(eng_mod, oracle, track, "cemppi", 1, 9001, 10, 4, B=1, steps=2, device_rng=True, sigma_est="mle")
+    run_case(eng_mod, oracle, track, "cmamppi", 1, 16384, 5, 3, B=1, steps=1)
+    run_case(eng_mod, oracle, track, "pmcmppi", 1, 16384, 10, 3, B=2, steps=1)
+    run_case(eng_mod, oracle, track, "pmcmppi", 1, 7169, 10, 4, B=1, steps=2, device_rng=True)
+
+
 @pytest.mark.parametrize("K,groups", [(256, 2), (256, 4), (1000, 2), (4096, 3), (4096, 0), (150, 0)])
 def test_pmcmppi_alias_table_parallel_equals_sequential(tmp_path, K, groups):
     """:pmcmppi builds the alias table (:804, StatsBase.make_alias_table!) with prefix scans instead of the sequential pairing loop and

@@ -17,15 +17,25 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _records(out):
+    """(compact, full): the ONE stdout line the driver parses, and the full record bench.py writes to stderr (BENCH_DETAIL ...) and gpurun_out/."""
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len([l for l in lines if l.startswith("{")]) == 1, out.stdout[-2000:]      # rank 0 prints exactly one JSON line
+    assert lines[-1].startswith("{") and len(lines[-1].encode()) < 6000               # ... it is the LAST line and fits what the driver keeps (round 5: 21.9 KB, parsed null)
+    det = [l for l in out.stderr.splitlines() if l.startswith("BENCH_DETAIL ")]
+    assert len(det) == 1
+    return json.loads(lines[-1]), json.loads(det[0][len("BENCH_DETAIL "):])
+
+
 def test_bench_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--repeats", "3"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 prints exactly one JSON line
-    d = json.loads(lines[0])
+    c, d = _records(out)
+    assert c["n_gpus"] == 2 and c["scaling"] == "weak" and c["value"] == pytest.approx(d["value"], rel=1e-6) and c["strong_scaling"]["trials_per_gpu"] == 32
+    assert c["summary_gather_path"] == d["summary_gather"] and c["rccl_ranks_seen"] is None and c["roofline"]["frac"] == pytest.approx(d["roofline"]["frac"], rel=1e-4)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "rollouts/s"
     assert d["config"]["trials_per_gpu"] == 64 and d["dtype"] == "f64" and d["vs_baseline"] is None
     # whole-job value: both ranks' rollouts over the max time
@@ -33,7 +43,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     s = d["strong_scaling"]
     assert s["total_trials"] == 64 and s["trials_per_gpu"] == 32 and s["value"] > 0
-    assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
+    assert d["summary_gather"].startswith("torch.distributed gather") and d["rccl_required"] is False      # gloo development backend: not strict by default
     r = d["roofline"]
     # roofline.frac: the one-stream isolation pass (three regions of 2 steps: one launch per AIS iteration, all 64 trials in it)
     assert r["rollouts_per_launch"] == 64 * 4096 and r["launches"] == 3 * 2 * 10 and 0 < r["frac"] < 1 and "one-stream pass" in r["kernel_isolation"]
@@ -53,9 +63,8 @@ def test_bench_self_launches_its_ranks():
            "--backend", "gloo", "--same-gpu", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    c, d = _records(out)
+    assert c["repeats"]["n"] == 3
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["strong_scaling"]["trials_per_gpu"] == 32
     assert d["repeats"]["n"] == 3 and d["repeats"]["ms_per_step"]["min"] <= d["repeats"]["ms_per_step"]["median"] <= d["repeats"]["ms_per_step"]["max"]
     assert d["summary_gather"].startswith("torch.distributed gather") or d["summary_gather"].startswith("mpopis_gather_summary")
@@ -66,9 +75,11 @@ def test_bench_single_gpu_line_has_every_baseline_config():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline", "--quick-configs"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    c, d = _records(out)
+    assert c["roofline"]["bound"] == "hbm" and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["avg_launch_us"] > 0 and c["config"]["trials_per_gpu"] == 64
+    assert c["midlap"]["closed_loop_ms"] > 0 and c["midlap"]["frozen_ms"] > 0 and [x["c"] for x in c["configs"]] == ["C2", "C3", "C4"]
+    assert [x["trials"] for x in c["c4"]] == [1] and 0 < c["c4"][0]["frac"] < 1 and c["detail"] == "gpurun_out/bench_detail_latest.json"
+    assert json.load(open(os.path.join(ROOT, c["detail"])))["value"] == d["value"]
     assert d["n_gpus"] == 1 and d["unit"] == "rollouts/s" and d["dtype"] == "f64"
     r = d["roofline"]
     assert 0 < r["step_frac"] < r["frac"] < 1
@@ -87,3 +98,19 @@ def test_bench_single_gpu_line_has_every_baseline_config():
         assert 0 < c["abi_sync_ms_per_step"] < 3 * c["ms_per_step"] + 0.2 and c["abi_sync"]["closed_loop"]["steps"] >= 5
         assert c["abi_sync"]["closed_loop"]["median"] <= 1.05 * c["abi_four_call_ms_per_step"]      # same loop, one wait instead of four
         assert c["resident_closed_loop_ms_per_step"] > 0
+        assert c["rollout_roofline"]["schedule"] == "one stream" and 0 < c["rollout_roofline"]["frac"] < 1
+
+
+def test_bench_strict_rccl_fails_instead_of_degrading():
+    """N > 1 with RCCL required (the default on the nccl backend; forced here on the gloo development backend): two ranks on ONE device cannot form an
+    RCCL communicator, so the run must FAIL (exit 3, reason on stderr, no JSON line) rather than report a number whose gather never went
+    through csrc/engine_comm.hip.  With --allow-gather-fallback the same command degrades and labels the line."""
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo", "--same-gpu", "--no-cpu-baseline", "--repeats", "0", "--require-rccl"]
+    out = subprocess.run(base + ["--master-port", str(_free_port())] + tail, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode != 0
+    assert "RCCL behind the C ABI is required" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run(base + ["--master-port", str(_free_port())] + tail + ["--allow-gather-fallback"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    c, d = _records(out)
+    assert c["summary_gather_path"].startswith("torch.distributed gather") and c["rccl_ranks_seen"] is None and d["rccl_required"] is False

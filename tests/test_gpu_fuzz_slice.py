@@ -56,7 +56,9 @@ def test_fuzz_slice_against_the_oracle(oracle, track):
     build.build()
     from mpopis_amd.engine import Engine
     from mpopis_amd._lib import MPOPISError
+    from tests.helpers import fuzz_case
     from tests.helpers.fuzz_case import run_case, tag_of
+    fuzz_case.waivers.clear()
     rng = np.random.default_rng(777)
     t0 = time.time()
     failed, ran = [], 0
@@ -67,3 +69,6 @@ def test_fuzz_slice_against_the_oracle(oracle, track):
         failed += msgs
     print("\n[fuzz slice] %d cases in %.0f s, %d failure message(s)" % (ran, time.time() - t0, len(failed)))
     assert not failed, failed[:8]
+    # braked-start slots accepted on the oracle's-own-conditioning yardstick instead of the plain 1e-5: a handful at most (round 5's slice: 0-2)
+    print("[fuzz slice] braked-start waivers used: %d" % len(fuzz_case.waivers))
+    assert len(fuzz_case.waivers) <= 3, fuzz_case.waivers[:6]

@@ -151,6 +151,7 @@ def test_gather_summary_through_the_abi(M):
     eng = Engine("car", 1, "gmppi", 64, 5, batch=3, lam=10.0, cov=[0.0625, 0.1])
     rec = np.arange(3 * RECORD_LEN, dtype=np.float64).reshape(3, RECORD_LEN)
     eng.comm_init(0, 1)
+    assert eng.comm_count() == 0                                        # no RCCL communicator behind the copy path
     parts = eng.gather_summary(rec, 5)                                  # n_max > n_local: padded rows are dropped again
     assert len(parts) == 1 and np.array_equal(parts[0], rec)
     eng.close()
@@ -158,6 +159,7 @@ def test_gather_summary_through_the_abi(M):
     uid = Engine.comm_unique_id()
     assert len(uid) == 128
     eng.comm_init(0, 1, uid)
+    assert eng.comm_count() == 1                                        # ncclCommCount of the real communicator
     parts = eng.gather_summary(rec, 3)
     assert len(parts) == 1 and np.array_equal(parts[0], rec)
     parts = eng.gather_summary(rec[:0], 3)                              # a rank without trials

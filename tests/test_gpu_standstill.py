@@ -57,7 +57,10 @@ def test_nominal_trajectory_brakes_to_a_stop(eng_mod, oracle, track, kind, K, N,
     uerr = float(np.max(np.abs(U_dev - pol.U)))
     print("\n[standstill] %s Vx0=%.1f pedal=%.1f: %d of %d rollouts reach |Vx| < 0.12; cost deviations > 1e-7: %d, > 1e-5: %d (max %.1e); control %.1e, U %.1e; oracle vs itself (U nudged 1e-13): %.1e"
           % (kind, vx0, pedal, int(stalled.sum()), K, int((rel > 1e-7).sum()), int((rel > 1e-5).sum()), rel.max(), cerr, uerr, sens))
-    assert cerr < max(1e-5, 10.0 * sens)                          # the contract, at the output that matters (or ten times the oracle's distance from itself)
+    if N == 1:
+        assert cerr < 1e-5                                        # the contract itself, hard, for the non-adaptive policy (measured 0: the weights collapse outside the class)
+    else:
+        assert cerr < max(1e-5, 10.0 * sens)                      # adaptive: the contract, or ten times the oracle's distance from itself at this state
     if chatter:
         assert stalled.sum() > K // 8                             # the case really is inside the chatter regime ...
         if N == 1:
