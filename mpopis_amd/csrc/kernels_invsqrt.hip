@@ -309,6 +309,112 @@ void debug_read_lprof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, 
 #define LPROFG(k_) do { } while (0)
 #endif
 // returns 1 when a cluster member gave up waiting for its partners (COOP only; the caller lets workgroup 0 of the cluster redo the slot alone), else 0
+// Workspace of slot b: Gs spill regions of (n + 1 + 128) n doubles (cooperative runs: one per workgroup), and never less than 2 n^2 doubles -- what the dense
+// fall-back (dense_invsqrt_slot: V and the working copy of A) needs when the quadrature cannot resolve the spectrum.
+__host__ __device__ inline size_t invsqrt_slot_doubles(int n, int Gs) {
+    const size_t a = (size_t)Gs * (size_t)(n + 1 + 128) * n, d = (size_t)2 * n * n;
+    return a > d ? a : d;
+}
+
+// ---- dense fall-back: A^-1/2 b and tr(A^-1) by a symmetric eigen-decomposition, for the (cold) case cond(A) > 1e14 ---------------------------------------
+// The reference forms Σ^-0.5 with eigen() (LinearAlgebra symmetric.jl, ^(A::Symmetric, p): src/mppi_mpopi_policies.jl:580), which has no conditioning limit;
+// the Lanczos + 64-node quadrature above resolves m/M down to 1e-14.  Beyond that ONE workgroup runs a cyclic two-sided Jacobi iteration on a copy M of A
+// (global workspace; the slot's Lanczos region is idle: its run never starts), accumulating V: the same method as the oracle's orc_sym_eig, in the parallel
+// round-robin order (n/2 disjoint rotations per round: phase 1 the angles, phase 2 the column rotations of M and V, phase 3 the row rotations of M) instead of
+// the row-cyclic one.  Stops like the oracle (off-diagonal mass <= 1e-30 of the diagonal's, at most 60 sweeps).  Then y = V diag(λ^-1/2) V' b, fro = sum 1/λ;
+// a non-positive eigenvalue is the reference's DomainError / the oracle's -2 (MPOPIS_ERR_NOT_PD).  ~0.1 s per call at n = 300: a cold path, not a fast one.
+__device__ __noinline__ void dense_invsqrt_slot(const double* __restrict__ A, const double* __restrict__ bv, double* M, double* V, double* __restrict__ y,
+                                                double* __restrict__ fro_out, int* __restrict__ status_b, int n, double* sh /* >= 3 n + 40 doubles of LDS */) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = kLanThreads;
+    const int ne = (n + 1) & ~1, np = ne / 2;
+    double* Cc = sh;                       // [np]
+    double* Ss = Cc + np;                  // [np]
+    int* Pq = reinterpret_cast<int*>(Ss + np);      // [2 np] ints
+    double* red = Ss + np + np + 2;        // [2 * kLanWaves]
+    double* ev = red + 2 * kLanWaves;      // [n]  (ev, then t = V' b scaled)
+    for (int e = tid; e < n * n; e += NT) { M[e] = A[e]; V[e] = (e / n == e % n) ? 1.0 : 0.0; }
+    __syncthreads();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int e = tid; e < n * n; e += NT) { const double v = M[e]; if (e / n == e % n) dg = fma(v, v, dg); else off = fma(v, v, off); }
+        off = wave_sum(off); dg = wave_sum(dg);
+        __syncthreads();
+        if (lane == 0) { red[wv] = off; red[kLanWaves + wv] = dg; }
+        __syncthreads();
+        off = 0.0; dg = 0.0;
+        for (int w = 0; w < kLanWaves; ++w) { off += red[w]; dg += red[kLanWaves + w]; }
+        if (off <= 1e-30 * (dg > 0.0 ? dg : 1.0) || !(off == off)) break;            // uniform: every thread sums the same partials in the same order
+        for (int r = 0; r < ne - 1; ++r) {
+            // ---- phase 1: the np disjoint pairs of round r (round-robin tournament) and their rotation angles
+            for (int k = tid; k < np; k += NT) {
+                int a = (k == 0) ? ne - 1 : (r + k) % (ne - 1);
+                int c = (k == 0) ? r : (r + ne - 1 - k) % (ne - 1);
+                int p = a < c ? a : c, q = a < c ? c : a;
+                double cc = 1.0, ss = 0.0;
+                if (q < n) {
+                    const double apq = M[p + (size_t)q * n];
+                    if (apq != 0.0) {
+                        const double app = M[p + (size_t)p * n], aqq = M[q + (size_t)q * n];
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        cc = 1.0 / sqrt(t * t + 1.0); ss = t * cc;
+                    }
+                } else { p = -1; }
+                Cc[k] = cc; Ss[k] = ss; Pq[2 * k] = p; Pq[2 * k + 1] = q;
+            }
+            __syncthreads();
+            // ---- phase 2: columns p, q of M and of V
+            for (int e = tid; e < np * n; e += NT) {
+                const int k = e / n, i = e - k * n, p = Pq[2 * k], q = Pq[2 * k + 1];
+                if (p < 0) continue;
+                const double cc = Cc[k], ss = Ss[k];
+                if (ss == 0.0) continue;
+                const double kp = M[i + (size_t)p * n], kq = M[i + (size_t)q * n], vp = V[i + (size_t)p * n], vq = V[i + (size_t)q * n];
+                M[i + (size_t)p * n] = cc * kp - ss * kq; M[i + (size_t)q * n] = ss * kp + cc * kq;
+                V[i + (size_t)p * n] = cc * vp - ss * vq; V[i + (size_t)q * n] = ss * vp + cc * vq;
+            }
+            __syncthreads();
+            // ---- phase 3: rows p, q of M (lanes along the pairs: neighbouring lanes touch different rows of the same column)
+            for (int e = tid; e < np * n; e += NT) {
+                const int j = e / np, k = e - j * np, p = Pq[2 * k], q = Pq[2 * k + 1];
+                if (p < 0) continue;
+                const double cc = Cc[k], ss = Ss[k];
+                if (ss == 0.0) continue;
+                const double pk = M[p + (size_t)j * n], qk = M[q + (size_t)j * n];
+                M[p + (size_t)j * n] = cc * pk - ss * qk; M[q + (size_t)j * n] = ss * pk + cc * qk;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- eigenvalues, y = V diag(λ^-1/2) V' b, fro = sum 1/λ
+    int bad = 0;
+    double fr = 0.0;
+    for (int j = tid; j < n; j += NT) { const double l = M[j + (size_t)j * n]; ev[j] = l; if (!(l > 0.0)) bad = 1; else fr += 1.0 / l; }
+    bad = __syncthreads_or(bad);
+    fr = wave_sum(fr);
+    if (lane == 0) red[wv] = fr;
+    __syncthreads();
+    if (bad) {
+        for (int i = tid; i < n; i += NT) y[i] = 0.0;
+        if (tid == 0) status_raise(status_b, MPOPIS_ERR_NOT_PD);
+        return;
+    }
+    if (tid == 0) { double t = 0.0; for (int w = 0; w < kLanWaves; ++w) t += red[w]; *fro_out = t; }
+    __syncthreads();
+    for (int j = wv; j < n; j += kLanWaves) {                    // t_j = (v_j . b) λ_j^-1/2: one wave per eigenvector
+        double t = 0.0;
+        for (int i = lane; i < n; i += 64) t = fma(V[i + (size_t)j * n], bv[i], t);
+        t = wave_sum(t);
+        if (lane == 0) ev[j] = t / sqrt(ev[j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s = fma(V[i + (size_t)j * n], ev[j], s);
+        y[i] = s;
+    }
+}
+
 template <bool COOP>
 __device__ __forceinline__ int lanczos_run(const int b, const int g, const double* __restrict__ Aall, const double* __restrict__ bvec, size_t bstride,
                                            const double* __restrict__ prep,
@@ -331,7 +437,7 @@ __device__ __forceinline__ int lanczos_run(const int b, const int g, const doubl
     __shared__ double red2[2][kLanWaves];
     const double* A = Aall + (size_t)b * n * n;
     const double* bv = bvec + (size_t)b * bstride;
-    double* Vg = Vall + ((size_t)b * Gs + g) * (size_t)(n + 1 + 128) * n;  // basis vectors v_0 .. v_n (only k >= nvl are ever touched); Gs regions per slot
+    double* Vg = Vall + (size_t)b * invsqrt_slot_doubles(n, Gs) + (size_t)g * (size_t)(n + 1 + 128) * n;  // basis vectors v_0 .. v_n (only k >= nvl are ever touched); Gs regions per slot
     double* pivg = Vg + (size_t)(n + 1) * n;                    // [2][n][64]
     double* y = yall + (size_t)b * n;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -377,10 +483,17 @@ __device__ __forceinline__ int lanczos_run(const int b, const int g, const doubl
         }
         return 0;
     }
-    if (!quad_ok) {                                             // spectrum bounds unusable (M/m beyond what the node table resolves)
+    if (!quad_ok) {                                             // spectrum bounds beyond what the node table resolves (M/m > 1e14) or unusable
         if (writer) {
-            for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
-            if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
+            if (Mhi == Mhi && mlo == mlo && Mhi < INFINITY && mlo > 0.0) {      // finite bounds: the dense fall-back (the reference's eigen-based Σ^-0.5 has no such limit)
+                if (tid == 0) msteps[b] = -1;
+                double* Vd = Vall + (size_t)b * invsqrt_slot_doubles(n, Gs);
+                __syncthreads();
+                dense_invsqrt_slot(A, bv, Vd + (size_t)n * n, Vd, y, &fro_out[b], &status[b], n, sh_lan);
+            } else {
+                for (int i = tid; i < n; i += kLanThreads) y[i] = 0.0;
+                if (tid == 0) { msteps[b] = 0; status_raise(&status[b], MPOPIS_ERR_NUMERIC); }
+            }
         }
         return 0;
     }
@@ -603,7 +716,7 @@ __global__ void __launch_bounds__(kLanThreads) k_lanczos_invsqrt(const double* _
     }
 }
 
-size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot) { return (size_t)B * regions_per_slot * (size_t)(n + 1 + 128) * n; }   // cooperative runs: one spill region per workgroup
+size_t invsqrt_workspace_doubles(int B, int n, int regions_per_slot) { return (size_t)B * invsqrt_slot_doubles(n, regions_per_slot); }   // cooperative runs: one spill region per workgroup
 int invsqrt_max_n() {
     // dynamic LDS of k_lanczos_invsqrt: (kLanWaves + 6) n + ... doubles, and of k_trtri_fro_pair: 16 (n + 31) + 1028 doubles, both <= 150 KiB
     return std::min((int)((150 * 1024 / 8 - 64 - kLanRed - 2 * kLanPivLds * 64) / (kLanWaves + 8)), (int)((150 * 1024 / 8 - 1028) / 16 - 31));

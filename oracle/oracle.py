@@ -230,6 +230,13 @@ class OraclePolicy:
         n = self.as_ if self.kind == "mppi" else self.cs
         return np.ctypeslib.as_array(self.p.Sigma, shape=(n, n)).T.copy()
 
+    @Sigma.setter
+    def Sigma(self, S):
+        """pol.Σ = S (full matrix; what mpopis_set_Sigma does on the engine side)"""
+        n = self.as_ if self.kind == "mppi" else self.cs
+        S = f64(S).reshape(n, n)
+        np.ctypeslib.as_array(self.p.Sigma, shape=(n, n))[:] = S.T
+
     @property
     def cma_ws(self):
         return np.ctypeslib.as_array(self.p.ws, shape=(self.K,)).copy()

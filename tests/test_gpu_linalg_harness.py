@@ -67,3 +67,18 @@ def _check(harness, B, n, env):
     assert _num(r"invsqrt applied twice: .* = ([0-9.e+-]+)", t) < 1e-9
     assert _num(r"status (-?\d+), tr", t) == 0
     assert _num(r"lanczos prep vs host: max rel ([0-9.e+-]+)", t) < 1e-12 and _num(r"usable (\d)", t) == 1   # spectrum bounds / quadrature nodes left by the trace launch
+
+
+@pytest.mark.parametrize("B,n,decades", [(2, 20, 17), (3, 100, 16), (2, 300, 18), (9, 300, 16), (2, 301, 20)])
+def test_dense_fallback_beyond_the_quadrature(harness, B, n, decades):
+    """cond(A) beyond 1e14 (A = D H D, variances graded over `decades` decades): the 64-node quadrature cannot resolve the spectrum and the Lanczos launch
+    hands the slot to the one-workgroup Jacobi eigen-solve (dense_invsqrt_slot) instead of reporting MPOPIS_ERR_NUMERIC -- the reference's eigen-based
+    Σ^-0.5 (:580) has no conditioning limit.  Applied twice the operator must invert A; its trace must agree with the triangular inverse's."""
+    r = subprocess.run([harness, str(B), str(n)], capture_output=True, text=True, timeout=300, env=dict(os.environ, KB_GRADE=str(decades)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    t = r.stdout
+    assert _num(r"potrf status min (-?\d+)", t) == 0
+    assert _num(r"msteps min (-?\d+)", t) == -1 and _num(r"msteps min -?\d+ max (-?\d+)", t) == -1           # every slot took the dense path
+    assert _num(r"status min (-?\d+), applied", t) == 0
+    assert _num(r"applied twice max .* = ([0-9.e+-]+),", t) < 1e-8
+    assert _num(r"triangular inverse rel ([0-9.e+-]+)", t) < 1e-9

@@ -508,22 +508,41 @@ def test_cma_posdef_error_matches_reference_behaviour(eng_mod, oracle, track):
 
 
 @pytest.mark.parametrize("ncars,T", [(1, 10), (3, 50)])
-def test_cma_numeric_error_when_the_spectrum_is_beyond_the_quadrature(eng_mod, track, ncars, T):
+def test_cma_beyond_the_quadrature_matches_the_oracles_eigen_path(eng_mod, oracle, track, ncars, T):
     """:cmamppi forms Σ^-0.5 δw (:580-581) with a 64-node quadrature of x^-1/2 on [m, M] (m = 1 / tr(Σ^-1), M = ||Σ||_inf) that resolves m / M down to
-    1e-14.  A proposal covariance beyond that (here diag entries 1 and 1e-16: its Cholesky factor exists) must be reported as MPOPIS_ERR_NUMERIC (-5)
-    -- the bounds and nodes are prepared by the last workgroup of the L^-1 trace launch (kernels_invsqrt.hip, lanczos_prep_slot), which has to hand the
-    verdict to the Lanczos kernel -- and the handle must keep working once a usable covariance is set (cs = 20: one workgroup; cs = 300: register
-    Cholesky + clusters)."""
+    1e-14.  Until round 5 a proposal covariance beyond that was reported as MPOPIS_ERR_NUMERIC (-5) where the reference's eigen-based Σ^-0.5 returns a
+    value; now the Lanczos launch hands such a slot to a one-workgroup Jacobi eigen-solve (kernels_invsqrt.hip, dense_invsqrt_slot).  Here: variances
+    graded over 17 decades (Cholesky factor exists; cond(Σ) ~ 1e17) against the oracle, whose Σ^-0.5 is orc_sym_pow (eigen-decomposition, like the
+    reference): same status, and on success the same control / pol.U / updated Σ (cs = 20: one workgroup; cs = 300: register Cholesky + clusters)."""
     from mpopis_amd._lib import MPOPISError
     cs = 2 * ncars * T
-    K = 256
-    eng = eng_mod.Engine("car", ncars, "cmamppi", K, T, batch=2, lam=10.0, ais_its=3, cma_sigma=0.75, cov=np.tile([0.0625, 0.1], ncars), track=track, seed=5)
-    d = np.ones(cs)
-    d[cs // 2] = 1e-16
-    eng.set_Sigma(np.diag(d))
-    with pytest.raises(MPOPISError) as ei:
-        eng.policy_step(None)
-    assert ei.value.code == -5, str(ei.value)
+    K, N = 256, 3
+    cov = np.tile([0.0625, 0.1], ncars)
+    d = np.tile([0.0625, 0.1], cs // 2) * 10.0 ** (-17.0 * np.arange(cs) / (cs - 1.0))
+    S = np.diag(d)
+    eng = eng_mod.Engine("car", ncars, "cmamppi", K, T, batch=2, lam=10.0, ais_its=N, cma_sigma=0.75, cov=cov, track=track, seed=5)
+    eng.set_Sigma(S)
+    Z = np.random.default_rng(3).standard_normal((2, N, K, cs))
+    refs = []
+    for b in range(2):
+        env = oracle.OracleEnv("car", ncars, track=track)
+        pol = oracle.OraclePolicy("cmamppi", env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, cma_sigma=0.75, nthreads=8)
+        pol.Sigma = S
+        refs.append((pol, pol(env, Z[b])))
+    worst = min(r["status"] for _, r in refs)
+    try:
+        got = eng.policy_step(Z)
+        code = 0
+    except MPOPISError as e:
+        code = e.code
+    assert code == worst, (code, worst)                      # never -5: the dense path answers where the quadrature cannot
+    if code == 0:
+        U = eng.get_U(); Sg = eng.get_Sigma()
+        for b, (pol, r) in enumerate(refs):
+            assert got["iters_run"][b] == r["iters_run"]
+            assert np.max(np.abs(got["control"][b] - r["control"])) < 1e-6
+            assert np.max(np.abs(U[b] - pol.U)) < 1e-6
+            assert np.max(np.abs(Sg[b] - r["Sigma_last"])) < 1e-6 * np.max(np.abs(r["Sigma_last"]))
     eng.reset()
     eng.set_Sigma(np.diag(np.tile([0.0625, 0.1], cs // 2)))
     got = eng.policy_step(None)

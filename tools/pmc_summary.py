@@ -43,9 +43,11 @@ if ro:
         tr = list(csv.DictReader(open(glob.glob(os.path.join(root, "*", "pmc_counter_collection.csv"))[0])))
         g = [int(x["Grid_Size"]) for x in tr if MATCH in x["Kernel_Name"] and x.get("Grid_Size")]
         if g:
-            B = max(1, round(sum(g) / len(g) / (K * CARS)))          # one lane per (sample, car)
+            B = max(1, round(sum(g) / len(g) / (K * CARS)))          # one lane per (sample, car) (multi-car waves leave 64 % CARS lanes idle: pass the trial count instead)
     except Exception:
         pass
+    if len(sys.argv) > 4:
+        B = int(sys.argv[4])                                         # trials per launch, stated by the caller
     known_read = B * cs * K * 8
     fetch_kib, write_kib = r.get("FETCH_SIZE") or 0.0, r.get("WRITE_SIZE") or 0.0
     sha = hashlib.sha256()

@@ -42,6 +42,6 @@ for P in "FETCH_SIZE" "WRITE_SIZE" \
     N=$(echo $P | cut -d" " -f1)
     rocprofv3 --pmc $P --kernel-trace --output-format csv -d "$O/pmc_c4/$N" -o pmc -- python "$R/tools/prof_c4.py" 64 3 > "$O/pmc_c4_$N.log" 2>&1
 done
-cd "$R" && python tools/pmc_summary.py "$O/pmc_c4" "${TAG}_c4_b64" c4 > "$O/pmc_c4_summary.log" 2>&1
+cd "$R" && python tools/pmc_summary.py "$O/pmc_c4" "${TAG}_c4_b64" c4 64 > "$O/pmc_c4_summary.log" 2>&1
 cp "$R"/profiles/${TAG}_c4_b64_pmc_summary.csv "$R"/profiles/pmc_rollout_3car.json "$O"/ 2>/dev/null
 rm -f "$O"/pmc_c4/*/pmc_counter_collection.csv "$O"/pmc_c4/*/pmc_kernel_trace.csv
