@@ -21,9 +21,10 @@
  *       MPOPIS_ERR_NOT_PD  (-2) PosDefException from MvNormal(Sigma')   :447,551,723,796
  *       MPOPIS_ERR_ACTION  (-3) "Action is not in action space" / NaN   src/envs/car_racing.jl:239
  *       MPOPIS_ERR_HIP     (-4) HIP runtime failure / no device
- *       MPOPIS_ERR_NUMERIC (-5) :cmamppi only: the iterative Σ^-0.5 δw (:580-581) did not reach 1e-13 within its step
- *                               budget (cond(Σ) far outside what CMA adaptation produces); the reference's eigen-based
- *                               Σ^-0.5 has no such limit, so this is reported instead of returning a wrong control
+ *       MPOPIS_ERR_NUMERIC (-5) :cmamppi only: Σ^-0.5 δw (:580-581) could not be formed because Σ, tr(Σ^-1) or δw is not finite.
+ *                               (Until ABI 4 also raised when cond(Σ) exceeded the 1e14 the Lanczos quadrature resolves; since ABI 5 such a
+ *                               slot is answered by a dense symmetric eigen-solve on the device, like the reference's eigen-based Σ^-0.5,
+ *                               and a non-positive eigenvalue there is MPOPIS_ERR_NOT_PD.)
  *     mpopis_last_error() returns a human readable message for the last failure.
  *   - a handle is not thread-safe; distinct handles are independent (own HIP stream).
  */
@@ -43,7 +44,8 @@ extern "C" {
  * 4: no new entry point; the execution knob mpopis_set_overlap changed: the default (on <= 0) is now the engine's own choice of schedule for the
  *    handle's shape instead of one stream, and on = 1 means "one stream" instead of "two halves".  Results never depended on the knob (bit-identical
  *    per slot in every schedule), so a version-3 caller sees the same numbers, sooner.
- * 5: + mpopis_comm_count (the number of ranks RCCL itself reports for the handle's communicator).  Nothing removed or changed in meaning. */
+ * 5: + mpopis_comm_count (the number of ranks RCCL itself reports for the handle's communicator).  Limits lifted, nothing changed in meaning: any K for
+ *    :cemppi / :cmamppi / :pmcmppi (were <= 8192 / 7168), and cond(Σ) beyond 1e14 under :cmamppi is computed instead of MPOPIS_ERR_NUMERIC. */
 #define MPOPIS_ABI_VERSION 5
 
 enum { MPOPIS_OK = 0, MPOPIS_ERR_ARG = -1, MPOPIS_ERR_NOT_PD = -2, MPOPIS_ERR_ACTION = -3, MPOPIS_ERR_HIP = -4, MPOPIS_ERR_NUMERIC = -5 };

@@ -135,7 +135,7 @@ static int fold_status(mpopis_handle* h, const int* per_slot) {
     for (int b = 0; b < h->B; ++b) st = mpopis::worse_status(st, per_slot[b]);
     if (st == MPOPIS_ERR_NOT_PD) h->err = "PosDefException: proposal covariance is not positive definite";
     else if (st == MPOPIS_ERR_ACTION) h->err = "Action is not in action space (non-finite control/cost)";
-    else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
+    else if (st == MPOPIS_ERR_NUMERIC) h->err = "cmamppi: Σ^-0.5 δw could not be formed (non-finite covariance, trace or δw)";
     return st;
 }
 

@@ -156,6 +156,6 @@ int mpopis_handle::run_trials(int num_steps, int laps, double* records, double* 
     }
     if (worst == MPOPIS_ERR_NOT_PD) err = "PosDefException: proposal covariance is not positive definite";
     else if (worst == MPOPIS_ERR_ACTION) err = "Action is not in action space (non-finite control/cost)";
-    else if (worst == MPOPIS_ERR_NUMERIC) err = "cmamppi: Σ^-0.5 δw did not converge (covariance too ill-conditioned)";
+    else if (worst == MPOPIS_ERR_NUMERIC) err = "cmamppi: Σ^-0.5 δw could not be formed (non-finite covariance, trace or δw)";
     return worst;
 }

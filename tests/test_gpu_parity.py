@@ -513,41 +513,41 @@ def test_cma_beyond_the_quadrature_matches_the_oracles_eigen_path(eng_mod, oracl
     1e-14.  Until round 5 a proposal covariance beyond that was reported as MPOPIS_ERR_NUMERIC (-5) where the reference's eigen-based Σ^-0.5 returns a
     value; now the Lanczos launch hands such a slot to a one-workgroup Jacobi eigen-solve (kernels_invsqrt.hip, dense_invsqrt_slot).  Here: variances
     graded over 17 decades (Cholesky factor exists; cond(Σ) ~ 1e17) against the oracle, whose Σ^-0.5 is orc_sym_pow (eigen-decomposition, like the
-    reference): same status, and on success the same control / pol.U / updated Σ (cs = 20: one workgroup; cs = 300: register Cholesky + clusters)."""
+    reference).  N = 2 -- ONE Σ^-0.5 δw, on the well-determined graded Σ, then the CMA update and the final draw from the updated Σ: strict parity (1e-7).
+    N = 3 forms a second Σ^-0.5 on the UPDATED Σ (the graded diagonal plus O(0.01) in every entry, :598): its smallest eigenvalues lie below ε ||Σ||, no
+    double-precision method determines them -- the reference's LAPACK eigen() included -- and two Jacobi orderings land 1e-6 ... 1e-4 apart on the control
+    (measured); what is asserted there is what IS determined: no error code, the same iteration count, finite outputs, agreement to 1e-2."""
     from mpopis_amd._lib import MPOPISError
     cs = 2 * ncars * T
-    K, N = 256, 3
+    K = 256
     cov = np.tile([0.0625, 0.1], ncars)
     d = np.tile([0.0625, 0.1], cs // 2) * 10.0 ** (-17.0 * np.arange(cs) / (cs - 1.0))
     S = np.diag(d)
-    eng = eng_mod.Engine("car", ncars, "cmamppi", K, T, batch=2, lam=10.0, ais_its=N, cma_sigma=0.75, cov=cov, track=track, seed=5)
-    eng.set_Sigma(S)
-    Z = np.random.default_rng(3).standard_normal((2, N, K, cs))
-    refs = []
-    for b in range(2):
-        env = oracle.OracleEnv("car", ncars, track=track)
-        pol = oracle.OraclePolicy("cmamppi", env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, cma_sigma=0.75, nthreads=8)
-        pol.Sigma = S
-        refs.append((pol, pol(env, Z[b])))
-    worst = min(r["status"] for _, r in refs)
-    try:
-        got = eng.policy_step(Z)
-        code = 0
-    except MPOPISError as e:
-        code = e.code
-    assert code == worst, (code, worst)                      # never -5: the dense path answers where the quadrature cannot
-    if code == 0:
+    for N, tol in ((2, 1e-7), (3, 1e-2)):
+        eng = eng_mod.Engine("car", ncars, "cmamppi", K, T, batch=2, lam=10.0, ais_its=N, cma_sigma=0.75, cov=cov, track=track, seed=5)
+        eng.set_Sigma(S)
+        Z = np.random.default_rng(3).standard_normal((2, N, K, cs))
+        refs = []
+        for b in range(2):
+            env = oracle.OracleEnv("car", ncars, track=track)
+            pol = oracle.OraclePolicy("cmamppi", env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, cma_sigma=0.75, nthreads=8)
+            pol.Sigma = S
+            refs.append((pol, pol(env, Z[b])))
+        assert min(r["status"] for _, r in refs) == 0
+        got = eng.policy_step(Z)                              # raises on any error code: never -5, the dense path answers where the quadrature cannot
         U = eng.get_U(); Sg = eng.get_Sigma()
         for b, (pol, r) in enumerate(refs):
-            assert got["iters_run"][b] == r["iters_run"]
-            assert np.max(np.abs(got["control"][b] - r["control"])) < 1e-6
-            assert np.max(np.abs(U[b] - pol.U)) < 1e-6
-            assert np.max(np.abs(Sg[b] - r["Sigma_last"])) < 1e-6 * np.max(np.abs(r["Sigma_last"]))
-    eng.reset()
-    eng.set_Sigma(np.diag(np.tile([0.0625, 0.1], cs // 2)))
-    got = eng.policy_step(None)
-    assert np.all(np.isfinite(got["control"])) and np.all(got["iters_run"] >= 1)
-    eng.close()
+            assert got["iters_run"][b] == r["iters_run"] == N
+            assert np.all(np.isfinite(got["control"][b])) and np.all(np.isfinite(Sg[b]))
+            assert np.max(np.abs(got["control"][b] - r["control"])) < tol
+            assert np.max(np.abs(U[b] - pol.U)) < tol
+            assert np.max(np.abs(Sg[b] - r["Sigma_last"])) < tol * np.max(np.abs(r["Sigma_last"]))
+        if N == 3:                                            # the handle keeps working once a usable covariance is set
+            eng.reset()
+            eng.set_Sigma(np.diag(np.tile([0.0625, 0.1], cs // 2)))
+            got = eng.policy_step(None)
+            assert np.all(np.isfinite(got["control"])) and np.all(got["iters_run"] >= 1)
+        eng.close()
 
 
 def test_other_track_through_loader(eng_mod, oracle, tmp_path):
