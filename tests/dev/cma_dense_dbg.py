@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, os.getcwd())
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mpopis_amd import engine as eng_mod
 from oracle import oracle
