@@ -42,7 +42,7 @@ def sig_err(a, b):
 def cost_err(pol, env, U_orig, cost_dev, ref, tol, worst):
     """max relative cost deviation over the well-conditioned rollouts.  A rollout that brakes to a standstill enters
     the reference's sign(Vx) chatter (the 22.5 kN brake force flips sign every Euler sub-step, src/envs/car_racing.jl:311):
-    any two IEEE-754 evaluation orders diverge there, so such rollouts -- identified from the
+    any two IEEE-754 evaluation orders diverge there (docs/history/round2.md), so such rollouts -- identified from the
     ORACLE's own trajectory, min |Vx| < 1e-3 m/s -- are only counted (must stay below 0.2 % of K)."""
     rel = np.abs(cost_dev - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)
     bad = np.where(rel >= tol)[0]

@@ -212,7 +212,7 @@ def test_C3_cemppi_midlap_states(eng_mod, oracle, track):
 
 def test_C4_cmamppi_3car_midlap_states(eng_mod, oracle, track):
     """configs[3] (3-car :cmamppi K=4096 N=10): 2 trials at closed-loop steps 10 / 25 / 40 (long :cmamppi loops end in the reference's own
-    PosDefException; whatever was reached is compared, at least 3 states)."""
+    PosDefException, docs/history/round3.md; whatever was reached is compared, at least 3 states)."""
     seed = 20243000
     kw = dict(elite_threshold=0.8, cma_sigma=0.75)
     states = harvest(eng_mod, track, "cmamppi", 3, 4096, 10, 2, (10, 25, 40), seed, **kw)
