@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     auto draw_chunk = [&](int j0) {                             // RNG: bz[q] = N(0,1) number (k0+li)*n + j0+4lk+q of the stream
         // (rows beyond n draw from counters past the sample's range: finite normals that meet the panel's zero columns beyond n, so nothing is zeroed here)
         const int kk = min(k0 + li, K - 1);
+#ifdef MPOPIS_DEV_NO_DRAW                                       // dev (tools/kbench_c5.hip): the kernel with the drawing compiled out = what a zero-cost generator would leave
+        bz[0] = bz[1] = bz[2] = bz[3] = (double)(kk + j0 + lk) * 1e-3;
+#else
         philox_normal_quad(seed, rng.slo, rng.shi, ((uint64_t)kk * n + j0 + 4 * lk) >> 2, sh_tab, bz);             // (4 | n: sample_trmm_fusable)
+#endif
     };
     // RNG: L comes as the pre-arranged, zero-filled panel copy the Cholesky kernel wrote (k_potrf_lds, Lpanel): row p of chunk c is LDS row p,
     // so staging is 8 plain loads + 8 plain LDS stores per thread and chunk (the generic path spends ~10 VALU per element on clamps,
@@ -363,9 +367,14 @@ __global__ void __launch_bounds__(ROWS ? 512 : 256, ROWS ? 1 : 2) k_wcov_mfma_pa
         }
     } else {
         for (int c0 = kbeg; c0 < kend; c0 += KC) {
+#ifdef MPOPIS_DEV_NO_STAGE                                      // dev (tools/kbench_c5.hip): only the first chunk is staged -- the MFMA + barrier floor of the kernel
+            if (c0 == kbeg) stage_chunk(Xs, c0);
+            __syncthreads();
+#else
             stage_chunk(Xs, c0);
             __syncthreads();
             if (c0 + KC < kend) load_chunk(c0 + KC);            // next chunk's loads fly during the MFMAs
+#endif
 #pragma unroll
             for (int kk0 = 0; kk0 < KC; kk0 += 4) {
 #pragma unroll
