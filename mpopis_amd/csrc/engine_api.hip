@@ -817,10 +817,11 @@ int mpopis_handle::auto_parts() const {
     return std::min(np, B);
 }
 
-// spin for `ticks` of the 100 MHz real-time counter (one wave)
-__global__ void k_spin_ticks(unsigned long long ticks) {
+// spin for `ticks` of the 100 MHz real-time counter (one wave) and leave the kernel's own [start, end] on that clock in ts[0..1]
+__global__ void k_spin_ticks(unsigned long long ticks, unsigned long long* ts) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (threadIdx.x == 0) { ts[0] = t0; ts[1] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 void mpopis_handle::verify_part_streams() {
@@ -828,12 +829,30 @@ void mpopis_handle::verify_part_streams() {
     static const int env_check = [] { const char* e = getenv("MPOPIS_STREAM_CHECK"); return e ? atoi(e) : 1; }();
     if (!env_check) return;
     constexpr double kSpinUs = 200.0;
-    auto concurrent = [&](const std::vector<hipStream_t>& ss) {          // do one spin kernel per stream overlap?  (wall time of all of them < 1.6 spins)
+    // Do one spin kernel per stream run at the same time?  Decided on the DEVICE's clock -- every kernel records its own [start, end] and the
+    // intervals must pairwise overlap by more than half a spin -- not on host wall time (until round 5: one host measurement against 1.6 spins, which
+    // a descheduled host thread or a busy GPU turns into a false "serialised": extra streams for the handle's lifetime and possibly max_parts = 1).
+    // Three probes, majority.
+    unsigned long long* d_ts = nullptr;
+    if (hipMalloc((void**)&d_ts, sizeof(unsigned long long) * 2 * (kMaxSplit + 1)) != hipSuccess) { (void)hipGetLastError(); return; }
+    auto probe = [&](const std::vector<hipStream_t>& ss) {
         for (auto s_ : ss) (void)hipStreamSynchronize(s_);
-        const auto t0 = std::chrono::steady_clock::now();
-        for (auto s_ : ss) hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, s_, (unsigned long long)(kSpinUs * 100.0));
+        for (size_t i = 0; i < ss.size(); ++i) hipLaunchKernelGGL(k_spin_ticks, dim3(1), dim3(64), 0, ss[i], (unsigned long long)(kSpinUs * 100.0), d_ts + 2 * i);
         for (auto s_ : ss) (void)hipStreamSynchronize(s_);
-        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 1.6 * kSpinUs;
+        std::vector<unsigned long long> ts(2 * ss.size());
+        if (hipMemcpy(ts.data(), d_ts, sizeof(unsigned long long) * ts.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        const long long need = (long long)(0.5 * kSpinUs * 100.0);
+        for (size_t i = 0; i < ss.size(); ++i)
+            for (size_t j = i + 1; j < ss.size(); ++j) {
+                const long long lo = (long long)std::max(ts[2 * i], ts[2 * j]), hi = (long long)std::min(ts[2 * i + 1], ts[2 * j + 1]);
+                if (hi - lo < need) return false;
+            }
+        return true;
+    };
+    auto concurrent = [&](const std::vector<hipStream_t>& ss) {
+        int yes = 0;
+        for (int r = 0; r < 3 && yes < 2 && r - yes < 2; ++r) yes += probe(ss) ? 1 : 0;
+        return yes >= 2;
     };
     { std::vector<hipStream_t> warm{stream}; (void)concurrent(warm); }   // (first launch of the kernel: code object load)
     std::vector<hipStream_t> chosen{stream};
@@ -852,6 +871,7 @@ void mpopis_handle::verify_part_streams() {
         else if (r < rejected_streams.size()) { xstream[i] = rejected_streams[r]; rejected_streams.erase(rejected_streams.begin() + r); }
     }
     max_parts = std::max(1, (int)chosen.size());
+    (void)hipFree(d_ts);
     (void)hipGetLastError();
 }
 
