@@ -78,7 +78,7 @@ def compact_line(out, detail_path=None):
         c["kernel_ms_per_step_one_stream"] = {k: _r(v, 4) for k, v in kms.items()}
     cb = out.get("cpu_baseline")
     if cb:
-        c["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "value_1thread", "mpc_steps_per_s")), "sample": str(cb.get("sample", ""))[:120]}
+        c["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "value_1thread", "mpc_steps_per_s")), "sample": str(cb.get("sample_short") or cb.get("sample", ""))[:120]}
     ag = out.get("max_rel_err_vs_cpu")
     if ag:
         c["max_rel_err_vs_cpu"] = _pick(ag, ("control", "cost", "iters_equal", "steps", "costs_off_by_more_than_1e-5"), 3)
@@ -281,6 +281,7 @@ def cpu_baseline(seconds_target=12.0, check_device=None):
             "value_1thread": N_AIS * K / t_one, "sample_1thread": "1 MPC step of 1 trial (%d rollouts), 1 thread, %.1f s" % (N_AIS * K, t_one),
             "sample": "%d MPC step(s) of 1 trial, same config (%d rollouts), C oracle + OpenMP over k, %.1f s (+%.1f s calibrating the thread count; host reports %d CPUs)"
                       % (r["steps"], r["steps"] * N_AIS * K, r["seconds"], t_cal, ncpu),
+            "sample_short": "%d MPC steps of 1 trial (%d rollouts), C oracle + OpenMP over k, %.1f s; host reports %d CPUs" % (r["steps"], r["steps"] * N_AIS * K, r["seconds"], ncpu),
             "mpc_steps_per_s": r["mpc_steps_per_s"], "thread_calibration_rollouts_per_s": table, "max_rel_err_vs_cpu": r.get("max_rel_err_vs_cpu")}
 
 
