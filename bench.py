@@ -583,6 +583,8 @@ def main():
 
         def run():
             try:
+                if cdev == "cuda":
+                    torch.cuda.set_device(local_rank)       # the current device is thread-local: a new thread starts on cuda:0, and the object broadcast below lands there
                 e.comm_init_from_dist(dist)
                 res["ok"] = True
             except Exception as ex:                  # noqa: BLE001
