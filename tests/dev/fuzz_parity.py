@@ -1,6 +1,7 @@
 """Randomised engine-vs-oracle parity sweep (test infrastructure: lives under tests/ because it uses the oracle; a fixed-seed slice of it runs
 in the GPU suite as tests/test_gpu_fuzz_slice.py).  Random policy / cars / K / T / N / B, random start states, injected or device noise, random
-multi-stream split.  usage: python tests/dev/fuzz_parity.py <n_cases> <seed>      (FUZZ_KINDS=pmcmppi,cmamppi restricts the policies)"""
+multi-stream split.  usage: python tests/dev/fuzz_parity.py <n_cases> <seed>      (FUZZ_KINDS=pmcmppi,cmamppi restricts the policies;
+FUZZ_BIGK=1: K beyond the one-workgroup sort / alias kernels -- 7169 ... 20000 -- at short horizons, the policies that sort or resample)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -25,6 +26,11 @@ for case in range(ncases):
     K = int(rng.choice([1, 2, 17, 64, 65, 150, 256, 700, 1024]))
     N = 1 if kind in ("gmppi", "mppi") else int(rng.integers(2, 5))
     B = int(rng.integers(1, 7))
+    if os.environ.get("FUZZ_BIGK"):
+        kind = str(rng.choice(["cemppi", "pmcmppi", "cmamppi", "pmcmppi", "cemppi", "musigmaaismppi"]))
+        K = int(rng.choice([7169, 8192, 8193, 9001, 12289, 16384, 20000]))
+        T, B, ncars = int(rng.choice([1, 3, 5, 8])), int(rng.integers(1, 4)), int(rng.choice([1, 1, 2, 3]))
+        N = int(rng.integers(2, 4))
     split = int(rng.choice([0, 2, 3, 4]))
     est = str(rng.choice(["mle", "ss", "lw", "rblw", "oas"])) if kind == "cemppi" else "mle"
     device_rng = bool(rng.integers(0, 2)) and kind != "mppi"
