@@ -792,7 +792,7 @@ def main():
                                    ("Car-Racing 1-car :μΣaismppi K=4096 H=50 N=10 λ=10 λ_ais=20, %d independent trials IN TOTAL = %d per GPU x %d GPUs (weak scaling of BASELINE configs[4]; "
                                     "configs[4] as written, 64 trials over all GPUs, is the `strong_scaling` block)" % (B * world, B, world)),
                        "total_trials": B * world,
-                       "trials_per_gpu": B, "rollouts_per_step": int(B * N_AIS * K), "prewarm_steps": PREWARM_STEPS, "parallelism": "trials sharded x%d, RCCL gather of summary stats" % world},
+                       "trials_per_gpu": B, "rollouts_per_step": int(B * N_AIS * K), "prewarm_steps": PREWARM_STEPS, "parallelism": ("trials sharded x%d, RCCL gather of summary stats" % world) if world > 1 else "one GPU: all trials resident, no collective"},
             "repeats": {"n": len(samples), "what": "the timed region repeated back to back (first sample = the contract's timed region = `value`)",
                         "ms_per_step": {"median": med / args.steps * 1e3, "min": srt[0] / args.steps * 1e3, "max": srt[-1] / args.steps * 1e3},
                         "value": {"median": total_rollouts / med, "max": total_rollouts / srt[0], "min": total_rollouts / srt[-1]}},
