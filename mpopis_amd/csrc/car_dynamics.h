@@ -347,7 +347,7 @@ MP_HD double tire_poly(double ta, double Ca, const TireK& k) {
 struct AxleForces { double fxf, fxr, fymf, fymr; };
 MP_HD AxleForces car_axle_forces(const CarParams& p, double pedal, double sg) {
     AxleForces a;
-    const double fx = fma(p.Fxmax, fmax(pedal, 0.0), p.Fxmin * fmin(pedal, 0.0) * sg);     // :310-312
+    const double fx = fma(p.Fxmax, fmax(pedal, 0.0), fma(p.Fxmin * fmin(pedal, 0.0), sg, pedal * 0.0));     // :310-312 (pedal * 0.0: a NaN pedal propagates, see car_action_consts)
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     a.fxf = lam * fx; a.fxr = (1 - lam) * fx;
     a.fymf = tire_fymax(fma(-p.mfz_f1, fx, p.mfz_f0), a.fxf);                                // :262-272 (same derived constants as the hot path)
@@ -364,7 +364,18 @@ MP_HD ActionConsts car_action_consts(const CarParams& p, double a1) {
     ActionConsts k;
     const double pedal = a1;                                                   // :297
     // forces and brush-model constants for sign(Vx) = +1, constant over the sub-steps (:310-318)
+    // fmax / fmin (v_max_f64 / v_min_f64) return the OTHER operand for a NaN: a NaN pedal would give fx = 0 and a finite rollout, where the reference's
+    // max(pedal, 0) propagates it and env(a) throws "Action is not in action space" (car_racing.jl:239, :310).  pedal * 0.0 is 0 for every finite pedal and
+    // NaN for a NaN one: as the addend of the second product it poisons fx -- and through it the state and the cost, which is what raises
+    // MPOPIS_ERR_ACTION -- for one multiply per action (found by tests/test_dynamics_shim.py, round 6).
+#ifndef MPOPIS_PEDAL_NAN
+#define MPOPIS_PEDAL_NAN 1
+#endif
+#if MPOPIS_PEDAL_NAN
+    const double fx = fma(p.Fxmax, fmax(pedal, 0.0), fma(p.Fxmin, fmin(pedal, 0.0), pedal * 0.0));
+#else
     const double fx = fma(p.Fxmax, fmax(pedal, 0.0), p.Fxmin * fmin(pedal, 0.0));
+#endif
     const double lam = (pedal <= 0) ? p.lbrake : p.ldrive;
     const double fxf = lam * fx, fxr = (1 - lam) * fx;
     k.pedal = pedal; k.fxf = fxf;

@@ -1,0 +1,86 @@
+"""CPU check (no GPU) of the engine's model step -- mpopis_amd/csrc/car_dynamics.h: car_action_step = ten car_substep's with the HOT force rules (forward, front
+slip in the forward half plane) and the GENERAL rules (stopped, sliding / rolling backwards, NaN) sharing one integration tail -- against the oracle's literal
+CarRacingEnv functor + _step! (src/envs/car_racing.jl:238-250,282-344: atan2 / tan / sincos per Euler sub-step).  The header is compiled for the host
+(tests/shim/host_shim.cpp, test infrastructure only); the device build differs from it only in the rcp / rsq seeds of its divisions and square roots.
+What this pins without a GPU: a regression of the general force rules (the cold lanes of a rollout that brakes to a standstill) shows up here as a state
+deviation far above rounding -- tests/test_gpu_standstill.py and the fuzz sweep only see it through costs and controls.  States: driving, crawling, exactly
+stopped, rolling backwards, spinning (|beta| large), full brake through Vx = 0, steering at the stops; actions incl. the clamp values."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHIM_SRC = os.path.join(HERE, "shim", "host_shim.cpp")
+SHIM_SO = os.path.join(HERE, "shim", "libhost_shim.so")
+HDR = os.path.join(os.path.dirname(HERE), "mpopis_amd", "csrc", "car_dynamics.h")
+dp = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    if (not os.path.exists(SHIM_SO)) or os.path.getmtime(SHIM_SO) < max(os.path.getmtime(SHIM_SRC), os.path.getmtime(HDR)):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", SHIM_SO, SHIM_SRC])
+    L = C.CDLL(SHIM_SO)
+    L.shim_car_action_step.argtypes = [dp, dp, C.c_double, C.c_double]
+    L.shim_car_action_step.restype = None
+    return L
+
+
+def _states(rng, n, regime):
+    s = np.zeros((n, 8))
+    s[:, 0] = rng.uniform(-50, 50, n); s[:, 1] = rng.uniform(-50, 50, n); s[:, 2] = rng.uniform(-np.pi, np.pi, n)
+    s[:, 6] = rng.uniform(-0.45, 0.45, n); s[:, 7] = rng.uniform(-1, 1, n)
+    if regime == "driving":
+        s[:, 3] = rng.uniform(2.0, 35.0, n); s[:, 4] = rng.uniform(-1.5, 1.5, n); s[:, 5] = rng.uniform(-0.8, 0.8, n)
+    elif regime == "crawling":
+        s[:, 3] = rng.uniform(1e-3, 1.2, n); s[:, 4] = rng.uniform(-0.3, 0.3, n); s[:, 5] = rng.uniform(-0.3, 0.3, n)
+    elif regime == "stopped":
+        s[:, 3] = 0.0; s[:, 4] = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(-0.2, 0.2, n)); s[:, 5] = np.where(rng.random(n) < 0.5, 0.0, rng.uniform(-0.2, 0.2, n))
+    elif regime == "backwards":
+        s[:, 3] = -rng.uniform(1e-3, 6.0, n); s[:, 4] = rng.uniform(-1.0, 1.0, n); s[:, 5] = rng.uniform(-0.6, 0.6, n)
+    elif regime == "spinning":
+        s[:, 3] = rng.uniform(-3.0, 8.0, n); s[:, 4] = rng.uniform(-8.0, 8.0, n); s[:, 5] = rng.uniform(-3.0, 3.0, n)
+    return s
+
+
+@pytest.mark.parametrize("regime", ["driving", "crawling", "stopped", "backwards", "spinning"])
+def test_model_step_matches_the_literal_reference_step(shim, oracle, regime):
+    rng = np.random.default_rng({"driving": 1, "crawling": 2, "stopped": 3, "backwards": 4, "spinning": 5}[regime])
+    p = oracle.car_default_params()
+    n = 1500
+    S = _states(rng, n, regime)
+    A = rng.uniform(-1, 1, (n, 2))
+    A[rng.random(n) < 0.15, 1] = -1.0                           # full brake (through Vx = 0 from the crawling states)
+    A[rng.random(n) < 0.10, 1] = 1.0
+    A[rng.random(n) < 0.10, 0] = rng.choice([-1.0, 1.0])
+    A[rng.random(n) < 0.05] = 0.0
+    worst, flips = 0.0, 0
+    scale = np.array([1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0])
+    for i in range(n):
+        ref = oracle.car_step(p, S[i], A[i])
+        got = S[i].copy()
+        shim.shim_car_action_step(p.ctypes.data_as(dp), got.ctypes.data_as(dp), float(A[i, 0]), float(A[i, 1]))
+        # three or four sub-steps later the two implementations may disagree about sign(Vx) when Vx passes within rounding of zero: the
+        # reference's brake force flips there (car_racing.jl:311) and the step's outcome differs by a whole sub-step's impulse -- counted, bounded
+        d = np.abs(got - ref) / np.maximum(scale, np.abs(ref))
+        d[2] = min(d[2], abs(abs(got[2] - ref[2]) - 2 * np.pi))  # the heading's wrap to (-pi, pi] may land on either side at exactly +-pi
+        if d.max() > 1e-9:
+            flips += 1
+            continue
+        worst = max(worst, float(d.max()))
+    print("\n[dynamics shim] %s: worst relative state deviation %.2e over %d states, %d set aside (sign(Vx) decided within rounding of zero)" % (regime, worst, n - flips, flips))
+    assert worst < 1e-11
+    assert flips <= (n // 100 if regime in ("crawling", "stopped") else 0)
+
+
+def test_nan_action_poisons_the_state_like_the_reference(shim, oracle):
+    """a NaN action is the reference's "Action is not in action space" error (car_racing.jl:239); in a rollout it must propagate into the state (and from
+    there into the cost) instead of being clamped away"""
+    p = oracle.car_default_params()
+    s = np.array([0.0, 0.0, 0.5, 10.0, 0.1, 0.05, 0.02, 0.3])
+    for a in ((float("nan"), 0.2), (0.1, float("nan"))):
+        got = s.copy()
+        shim.shim_car_action_step(p.ctypes.data_as(dp), got.ctypes.data_as(dp), a[0], a[1])
+        assert np.isnan(got[[0, 1, 3, 4, 5]]).any()

@@ -240,6 +240,30 @@ def test_device_rng_normals_full_size(eng_mod, oracle, track):
     eng.close()
 
 
+@pytest.mark.parametrize("ncars,K,entry", [(1, 64, 0), (1, 64, 1), (1, 4096, 1), (1, 4096, 3), (3, 512, 3), (3, 512, 4)])
+def test_nan_control_in_a_rollout_is_an_action_error(eng_mod, ncars, K, entry, track):
+    """A NaN in pol.U reaches every rollout as a NaN action: the reference's env(a) throws "Action is not in action space" (car_racing.jl:239) -- the engine
+    must report MPOPIS_ERR_ACTION (-3), not a finite cost.  Round 6 found that a NaN PEDAL alone did not: fmax / fmin (v_max_f64 / v_min_f64) return the other
+    operand for a NaN, the drive force became 0 and the rollout stayed finite (tests/test_dynamics_shim.py found it on the CPU); steering entries always
+    poisoned the state.  Entries 0 / 1 / 3 / 4 = steer and pedal of the first steps (and of the second car), one-wave and two-wave rollout kernels (K)."""
+    from mpopis_amd._lib import MPOPISError
+    T = 10
+    cs = 2 * ncars * T
+    eng = eng_mod.Engine("car", ncars, "gmppi", K, T, batch=2, lam=10.0, cov=np.tile([0.0625, 0.1], ncars), track=track, seed=11)
+    got = eng.policy_step(None)                               # a clean step first: finite
+    assert np.all(np.isfinite(got["cost"]))
+    U = np.zeros((2, cs))
+    U[1, entry] = np.nan                                      # slot 1 only
+    eng.set_U(U)
+    with pytest.raises(MPOPISError) as ei:
+        eng.policy_step(None)
+    assert ei.value.code == -3, str(ei.value)
+    eng.set_U(np.zeros((2, cs)))                              # the handle keeps working
+    got = eng.policy_step(None)
+    assert np.all(np.isfinite(got["cost"])) and np.all(np.isfinite(got["control"]))
+    eng.close()
+
+
 def test_env_step_and_errors(eng_mod, oracle, track):
     from mpopis_amd._lib import MPOPISError
     eng = eng_mod.Engine("car", 3, "gmppi", 64, 5, batch=2, lam=10.0, cov=np.tile([0.0625, 0.1], 3), track=track)

@@ -8,9 +8,9 @@ eng.bench_policy_steps(3)
 eng.timing_enable(2); eng.timing_reset()
 ms, rl = eng.bench_policy_steps(20)
 tm = eng.timing_read()
-print("single stream: %.3f ms/step, rollout kernel %.1f us avg over %d launches" % (ms / 20, tm["rollout"][0] / tm["rollout"][1] * 1e3, tm["rollout"][1]))
+one = "single stream: %.3f ms/step, rollout kernel %.1f us avg over %d launches" % (ms / 20, tm["rollout"][0] / tm["rollout"][1] * 1e3, tm["rollout"][1])
 eng.set_overlap(-1); eng.timing_enable(False)
 eng.bench_policy_steps(3)
 ms, rl = eng.bench_policy_steps(20)
-print("default schedule: %.3f ms/step  %.3e rollouts/s" % (ms / 20, rl / (ms * 1e-3)))
+print(one + " | default schedule: %.3f ms/step  %.3e rollouts/s" % (ms / 20, rl / (ms * 1e-3)))
 eng.close()
