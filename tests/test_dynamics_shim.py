@@ -84,3 +84,55 @@ def test_nan_action_poisons_the_state_like_the_reference(shim, oracle):
         got = s.copy()
         shim.shim_car_action_step(p.ctypes.data_as(dp), got.ctypes.data_as(dp), a[0], a[1])
         assert np.isnan(got[[0, 1, 3, 4, 5]]).any()
+
+
+def test_reward_matches_the_reference_reward(shim, oracle):
+    """car_reward (ratio test for |beta| > beta_limit, squared-distance neighbour choice, rsq / rcp-free on the host) against the oracle's literal reward
+    (src/envs/car_racing.jl:201-213: atan2, findmin, norms) on the default track: on the road, off the road (-1e6), beyond the slip-angle limit (-5000),
+    slow and reversed cars."""
+    shim.shim_car_reward.argtypes = [dp, C.c_int, dp, dp, dp, dp]
+    shim.shim_car_reward.restype = C.c_double
+    p = oracle.car_default_params()
+    track = oracle.load_track()
+    tx, ty, tw = (np.ascontiguousarray(a, dtype=np.float64) for a in track)
+    env = oracle.OracleEnv("car", 1, track=track)
+    rng = np.random.default_rng(9)
+    worst, seen = 0.0, set()
+    for i in range(4000):
+        j = int(rng.integers(0, len(tx)))
+        off = rng.normal(0.0, 6.0, 2) if i % 4 else rng.normal(0.0, 25.0, 2)          # mostly inside the lane, a quarter far off
+        s = np.array([tx[j] + off[0], ty[j] + off[1], rng.uniform(-np.pi, np.pi), rng.uniform(-3, 30), rng.uniform(-6, 6), rng.uniform(-1, 1), rng.uniform(-0.4, 0.4), rng.uniform(-1, 1)])
+        env.state = s
+        ref = env.reward()
+        got = shim.shim_car_reward(p.ctypes.data_as(dp), len(tx), tx.ctypes.data_as(dp), ty.ctypes.data_as(dp), tw.ctypes.data_as(dp), s.ctypes.data_as(dp))
+        seen.add((ref < -9e5, -9e5 <= ref < -4000))
+        worst = max(worst, abs(got - ref) / max(1.0, abs(ref)))
+    assert worst < 1e-12, worst
+    assert len(seen) >= 3                                              # on the road, off the road and beyond the slip limit all occurred
+
+
+def test_mountaincar_step_and_reward_match_the_oracle(shim, oracle):
+    """mc_step / mc_reward (car_dynamics.h) against the oracle's MountainCar (RL.jl MountainCarEnv(continuous = true) + the reward override of
+    src/examples/mountaincar_example.jl:4-22) along closed-loop runs with random forces, through the goal and the step limit."""
+    shim.shim_mc_step.argtypes = [dp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double]
+    shim.shim_mc_step.restype = None
+    shim.shim_mc_reward.argtypes = [dp, dp, C.c_int]
+    shim.shim_mc_reward.restype = C.c_double
+    p = oracle.mountaincar_default_params()
+    rng = np.random.default_rng(4)
+    done_seen = 0
+    for run in range(40):
+        env = oracle.OracleEnv("mountaincar")
+        s = env.state.copy()
+        t, done = C.c_int(0), C.c_int(0)
+        for step in range(250):
+            f = float(np.clip(rng.normal(0.6 if run % 2 else 0.0, 0.8), -1, 1))
+            env.step([f])
+            shim.shim_mc_step(p.ctypes.data_as(dp), s.ctypes.data_as(dp), C.byref(t), C.byref(done), f)
+            assert np.max(np.abs(s - env.state)) < 1e-14
+            r = shim.shim_mc_reward(p.ctypes.data_as(dp), s.ctypes.data_as(dp), done.value)
+            assert abs(r - env.reward()) <= 1e-12 * max(1.0, abs(env.reward()))
+            if done.value:
+                done_seen += 1
+                break
+    assert done_seen >= 5
