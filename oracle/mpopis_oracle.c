@@ -317,12 +317,16 @@ void orc_compute_weights(double lambda, const double *cost, int K, double *w) {
 /* :129-144 */
 double orc_rollout_model(orc_env *e, int T, const double *controls, double *traj_log) {
     double traj_cost = 0.0;
+    int thrown = 0;
     for (int t = 0; t < T; ++t) {
-        orc_env_step(e, controls + (size_t)t * e->as);
+        /* env(controls) throws "Action is not in action space" for a NaN control (car_racing.jl:239; clamp passes NaN through): the whole pol(env)
+         * call dies there.  A restated rollout cannot throw out of an OpenMP loop, so the rollout's cost is poisoned instead and the caller turns a
+         * non-finite cost into status -3 (round 6: the return code used to be dropped here, a NaN control gave status 0 and a finite cost). */
+        if (orc_env_step(e, controls + (size_t)t * e->as)) thrown = 1;
         traj_cost -= orc_env_reward(e);
         if (traj_log) memcpy(traj_log + (size_t)t * e->ss, e->state, sizeof(double) * e->ss);
     }
-    return traj_cost;
+    return thrown ? NAN : traj_cost;
 }
 
 int orc_m_elite(int K, double thr) { return (int)nearbyint(K * (1 - thr)); }       /* policies.jl:437,515 */
@@ -905,6 +909,8 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
         lmul_LZ(cs, K, L, nz->Z + (size_t)(n - 1) * cs * K, E);                    /* E = rand(rng,P,K) */
         orc_simulate_model(pol, Ucur, env, E, Sinv, U_orig, cost, NULL);
         out->iters_run = n;
+        for (int k = 0; k < K; ++k) if (!(fabs(cost[k]) < INFINITY)) status = -3;    /* a rollout's env(a) threw (orc_rollout_model), or a NaN state poisoned the reward */
+        if (status) break;
         if (n < N) {
             if (kind == ORC_POL_IMPPI || kind == ORC_POL_MUAISMPPI || kind == ORC_POL_MUSIGMAAISMPPI) {
                 double lam = (kind == ORC_POL_IMPPI) ? pol->lambda : pol->lambda_ais;   /* :362 / :660 / :730 */

@@ -241,7 +241,7 @@ def test_device_rng_normals_full_size(eng_mod, oracle, track):
 
 
 @pytest.mark.parametrize("ncars,K,entry", [(1, 64, 0), (1, 64, 1), (1, 4096, 1), (1, 4096, 3), (3, 512, 3), (3, 512, 4)])
-def test_nan_control_in_a_rollout_is_an_action_error(eng_mod, ncars, K, entry, track):
+def test_nan_control_in_a_rollout_is_an_action_error(eng_mod, oracle, ncars, K, entry, track):
     """A NaN in pol.U reaches every rollout as a NaN action: the reference's env(a) throws "Action is not in action space" (car_racing.jl:239) -- the engine
     must report MPOPIS_ERR_ACTION (-3), not a finite cost.  Round 6 found that a NaN PEDAL alone did not: fmax / fmin (v_max_f64 / v_min_f64) return the other
     operand for a NaN, the drive force became 0 and the rollout stayed finite (tests/test_dynamics_shim.py found it on the CPU); steering entries always
@@ -258,6 +258,12 @@ def test_nan_control_in_a_rollout_is_an_action_error(eng_mod, ncars, K, entry, t
     with pytest.raises(MPOPISError) as ei:
         eng.policy_step(None)
     assert ei.value.code == -3, str(ei.value)
+    # the oracle says the same (single car: env(a) throws; its multi-car env does not check, like the reference's functor, multi-car_racing.jl:204 --
+    # there the NaN state poisons the cost and the non-finite cost is the error)
+    env = oracle.OracleEnv("car", ncars, track=track)
+    pol = oracle.OraclePolicy("gmppi", env, 64, T, lam=10.0, U0=np.zeros(2 * ncars), cov=np.tile([0.0625, 0.1], ncars))
+    pol.U = U[1]
+    assert pol(env, np.random.default_rng(0).standard_normal((1, 64, cs)))["status"] == -3
     eng.set_U(np.zeros((2, cs)))                              # the handle keeps working
     got = eng.policy_step(None)
     assert np.all(np.isfinite(got["cost"])) and np.all(np.isfinite(got["control"]))
