@@ -991,6 +991,10 @@ int orc_policy_call(orc_policy *pol, const orc_env *env, const orc_noise *nz, or
                     int h_sigma = (nps / sqrt(1 - pow(1 - c_s, 2.0 * n)) < (1.4 + 2.0 / (cs + 1)) * E_cma) ? 1 : 0; /* :585 */
                     double sS = h_sigma * sqrt(c_S * (2 - c_S) * mu_eff);
                     for (int i = 0; i < cs; ++i) p_Sigma[i] = (1 - c_S) * p_Sigma[i] + sS * dw[i];   /* :586 */
+                    /* δs[order[ii]] (:593) is a LINEAR index up to K into the cs x m_elite matrix: Julia throws BoundsError when cs*m_elite < K
+                     * (the engine refuses such a handle at creation with MPOPIS_ERR_ARG and the same message).  Until round 6 this loop read past
+                     * `elite` in that case. */
+                    if ((long long)cs * m_elite < K) { status = -1; break; }
                     double normC = 0.0;                 /* Frobenius pieces of norm(C*scalar) */
                     double temp_sum = 0.0;                                         /* :588-596 (scalar! quirk) */
                     for (int ii = 0; ii < K; ++ii) {

@@ -1,0 +1,63 @@
+"""Engine (through the C ABI) vs the oracle at the EDGES of the parameter ranges -- what the randomised sweep does not draw: degenerate elite sets (none, one,
+all of the samples), a single sample, extreme lambda, alpha != 1 under adaptive policies, a one-step horizon.  The two must agree on the outcome class
+(status code: -2 where the reference's MvNormal throws PosDefException, -1 where its delta_s[order[ii]] indexing throws BoundsError, :593) and, where the call
+succeeds, on iteration count and control."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(kind="cemppi", K=150, T=10, N=4, elite_threshold=1.0),                 # no elite sample: mean of nothing -> NaN covariance -> PosDefException
+    dict(kind="cemppi", K=150, T=10, N=4, elite_threshold=0.995),               # one elite sample
+    dict(kind="cemppi", K=150, T=10, N=4, elite_threshold=0.0),                 # every sample is elite
+    dict(kind="cemppi", K=150, T=10, N=4, elite_threshold=0.5, sigma_est="oas"),
+    dict(kind="cmamppi", K=150, T=10, N=3, elite_threshold=0.99),               # cs * m_elite < K: BoundsError (:593)
+    dict(kind="cmamppi", K=150, T=10, N=3, elite_threshold=0.0),
+    dict(kind="musigmaaismppi", K=2, T=10, N=3),
+    dict(kind="musigmaaismppi", K=1, T=10, N=3),
+    dict(kind="pmcmppi", K=2, T=10, N=3),
+    dict(kind="pmcmppi", K=1, T=5, N=3),                                        # corrected covariance of one column: 0/0 -> PosDefException
+    dict(kind="musigmaaismppi", K=256, T=10, N=3, lam=1e-6, lam_ais=1e-6),      # the weights collapse onto the best sample
+    dict(kind="musigmaaismppi", K=256, T=10, N=3, lam=1e12, lam_ais=1e12),      # uniform weights
+    dict(kind="muaismppi", K=256, T=10, N=3, alpha=0.3),                        # control-cost term (gamma != 0) through the AIS iterations
+    dict(kind="cemppi", K=256, T=10, N=3, alpha=0.0),
+    dict(kind="gmppi", K=64, T=1, N=1),                                         # horizon 1: the roll of pol.U degenerates (utils.jl:98)
+    dict(kind="imppi", K=64, T=1, N=3),
+]
+
+
+@pytest.mark.parametrize("c", CASES, ids=["%s-%s" % (c["kind"], "-".join("%s=%s" % kv for kv in c.items() if kv[0] not in ("kind", "T", "N"))) for c in CASES])
+def test_edge_configuration_agrees_with_the_oracle(oracle, track, c):
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    from mpopis_amd._lib import MPOPISError
+    kind, K, T, N = c["kind"], c["K"], c["T"], c["N"]
+    kw = {k: v for k, v in c.items() if k not in ("kind", "K", "T", "N")}
+    lam, lam_ais, alpha = kw.pop("lam", 10.0), kw.pop("lam_ais", 20.0), kw.pop("alpha", 1.0)
+    cs = 2 * T
+    rng = np.random.default_rng(1000 + K + T)
+    Z = rng.standard_normal((1, N if kind != "gmppi" else 1, K, cs))
+    di = rng.integers(0, K, (1, max(N - 1, 1), K)).astype(np.int32)
+    du = rng.random((1, max(N - 1, 1), K))
+    env = oracle.OracleEnv("car", 1, track=track)
+    pol = oracle.OraclePolicy(kind, env, K, T, lam=lam, alpha=alpha, U0=np.zeros(2), cov=[0.0625, 0.1], N=N, lam_ais=lam_ais, cma_sigma=0.75, **kw)
+    ref = pol(env, Z[0], di[0], du[0])
+    try:
+        eng = Engine("car", 1, kind, K, T, batch=1, lam=lam, alpha=alpha, ais_its=N, lam_ais=lam_ais, cma_sigma=0.75, cov=[0.0625, 0.1], track=track, **kw)
+    except MPOPISError as e:
+        # the one configuration the engine refuses up front: the reference would throw at its first update (BoundsError), the oracle reports it there
+        assert e.code == -1 and "BoundsError" in str(e) and ref["status"] == -1
+        return
+    try:
+        got = eng.policy_step(Z, di, du)
+        code = 0
+    except MPOPISError as e:
+        got, code = None, e.code
+    eng.close()
+    assert code == ref["status"], (code, ref["status"])
+    if code == 0:
+        assert int(got["iters_run"][0]) == ref["iters_run"]
+        assert np.all(np.isfinite(got["control"][0])) and np.max(np.abs(got["control"][0] - ref["control"])) < 1e-9
+        assert np.max(np.abs(got["cost"][0] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)) < 1e-7
