@@ -449,6 +449,10 @@ __global__ void __launch_bounds__(64) k_rollout_simple(RolloutArgs a) {
         const double v = Ub[t] + Eb[(size_t)t * K];
         if (gv) cc += gv[t] * (v - Uo[t]);
         const double act = clampd(v, a.env.lo[0], a.env.hi[0]);
+        // a NaN action: RL.jl's act! asserts `a in action_space(env)` and the rollout dies there.  MountainCar's reward carries the NaN state into the cost by
+        // itself; CartPole's reward (1 until done) does not look at the state's values, so the cost is poisoned explicitly -- a non-finite cost is what raises
+        // MPOPIS_ERR_ACTION (round 6, tests/test_gpu_edge_cases.py)
+        if (act != act) cost = act;
         simple_env_step(a.env, s, &t_env, &done, act);
         cost -= simple_env_reward(a.env, s, done);
         if (tr && valid) {

@@ -61,3 +61,59 @@ def test_edge_configuration_agrees_with_the_oracle(oracle, track, c):
         assert int(got["iters_run"][0]) == ref["iters_run"]
         assert np.all(np.isfinite(got["control"][0])) and np.max(np.abs(got["control"][0] - ref["control"])) < 1e-9
         assert np.max(np.abs(got["cost"][0] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)) < 1e-7
+
+
+@pytest.mark.parametrize("kind,ncars", [("gmppi", 1), ("musigmaaismppi", 1), ("cemppi", 3)])
+def test_custom_action_bounds_reach_rollouts_and_control(oracle, track, kind, ncars):
+    """mpopis_set_action_bounds = the bounds get_model_controls and the final clamp take from action_space(env) (src/utils.jl:103-116, :91): narrower, asymmetric
+    bounds must clamp every rollout's controls and the returned control exactly as the oracle's do (per car for the multi-car env)."""
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    K, T, N = 256, 12, 3
+    cs = 2 * ncars * T
+    cov = np.tile([0.25, 0.4], ncars)                          # wide noise: most samples hit a bound somewhere
+    lo = np.tile([-0.5, -0.2], ncars) - 0.05 * np.arange(2 * ncars)
+    hi = np.tile([0.3, 0.9], ncars) - 0.03 * np.arange(2 * ncars)
+    eng = Engine("car", ncars, kind, K, T, batch=2, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, cov=cov, track=track, seed=3)
+    eng.set_action_bounds(lo, hi)
+    rng = np.random.default_rng(21)
+    Z = rng.standard_normal((2, N if kind != "gmppi" else 1, K, cs))
+    got = eng.policy_step(Z)
+    for b in range(2):
+        env = oracle.OracleEnv("car", ncars, track=track)
+        pol = oracle.OraclePolicy(kind, env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0, elite_threshold=0.8)
+        for i in range(2 * ncars):
+            pol.p.lo[i] = lo[i]; pol.p.hi[i] = hi[i]
+        ref = pol(env, Z[b])
+        assert ref["status"] == 0 and int(got["iters_run"][b]) == ref["iters_run"]
+        assert np.max(np.abs(got["cost"][b] - ref["cost"]) / (np.abs(ref["cost"]) + 1e-9)) < 1e-7
+        assert np.max(np.abs(got["control"][b] - ref["control"])) < 1e-9
+        assert np.all(got["control"][b] >= lo - 1e-15) and np.all(got["control"][b] <= hi + 1e-15)
+    # and the bounds bite: with the default [-1, 1] the same noise gives other costs
+    eng.set_action_bounds(-np.ones(2 * ncars), np.ones(2 * ncars))
+    eng.reset(); eng.set_U(np.zeros((2, cs)))
+    assert not np.allclose(eng.policy_step(Z)["cost"], got["cost"])
+    eng.close()
+
+
+@pytest.mark.parametrize("env_kind", ["mountaincar", "cartpole"])
+def test_nan_control_in_the_scalar_action_envs(oracle, env_kind):
+    """the same for the RL.jl adapters (k_rollout_simple): a NaN force reaches every rollout, the reference's act! rejects it; engine and oracle report -3"""
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    from mpopis_amd._lib import MPOPISError
+    K, T = 20, 15
+    eng = Engine(env_kind, 1, "gmppi", K, T, batch=2, lam=0.1, cov=[1.5], seed=2)
+    assert np.all(np.isfinite(eng.policy_step(None)["cost"]))
+    U = np.zeros((2, T)); U[0, 3] = np.nan
+    eng.set_U(U)
+    with pytest.raises(MPOPISError) as ei:
+        eng.policy_step(None)
+    assert ei.value.code == -3
+    eng.close()
+    env = oracle.OracleEnv(env_kind)
+    pol = oracle.OraclePolicy("gmppi", env, K, T, lam=0.1, U0=np.zeros(1), cov=[1.5])
+    pol.U = U[0]
+    assert pol(env, np.random.default_rng(0).standard_normal((1, K, T)))["status"] == -3
