@@ -1,7 +1,8 @@
 """Randomised engine-vs-oracle parity sweep (test infrastructure: lives under tests/ because it uses the oracle; a fixed-seed slice of it runs
 in the GPU suite as tests/test_gpu_fuzz_slice.py).  Random policy / cars / K / T / N / B, random start states, injected or device noise, random
 multi-stream split.  usage: python tests/dev/fuzz_parity.py <n_cases> <seed>      (FUZZ_KINDS=pmcmppi,cmamppi restricts the policies;
-FUZZ_BIGK=1: K beyond the one-workgroup sort / alias kernels -- 7169 ... 20000 -- at short horizons, the policies that sort or resample)"""
+FUZZ_BIGK=1: K beyond the one-workgroup sort / alias kernels -- 7169 ... 20000 -- at short horizons, the policies that sort or resample;
+FUZZ_WILD=1: lambda, alpha, lambda_ais, the elite threshold and the CMA step size drawn off their defaults)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -37,6 +38,11 @@ for case in range(ncases):
     if kind == "cmamppi" and 2 * ncars * T * round(0.2 * K) < K:
         continue
     c = dict(kind=kind, ncars=ncars, K=K, T=T, N=N, B=B, split=split, est=est, device_rng=device_rng, seed=int(rng.integers(1, 2 ** 31)))
+    if os.environ.get("FUZZ_WILD"):                             # the policies' own parameters off their defaults
+        c.update(lam=float(10.0 ** rng.uniform(-1, 3)), alpha=float(rng.choice([1.0, 1.0, 0.9, 0.5, 0.0])), lam_ais=float(10.0 ** rng.uniform(0, 3)),
+                 elite=float(rng.choice([0.5, 0.8, 0.9, 0.95])), cma_sigma=float(rng.choice([0.5, 0.75, 1.0, 1.5])))
+        if kind == "cmamppi" and 2 * ncars * T * round((1 - c["elite"]) * K) < K:
+            continue
     st, msgs = run_case(O, Engine, MPOPISError, track, c, rng)
     for m in msgs:
         print(m)

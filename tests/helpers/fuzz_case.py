@@ -12,19 +12,21 @@ waivers = []
 
 
 def tag_of(c):
-    return "%s cars=%d K=%d T=%d N=%d B=%d split=%d est=%s rng=%s seed=%d" % (c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"], c["split"], c["est"],
-                                                                                "dev" if c["device_rng"] else "inj", c["seed"])
+    extra = "".join(" %s=%g" % (k, c[k]) for k in ("lam", "alpha", "lam_ais", "elite", "cma_sigma") if k in c)
+    return "%s cars=%d K=%d T=%d N=%d B=%d split=%d est=%s rng=%s seed=%d%s" % (c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"], c["split"], c["est"],
+                                                                                  "dev" if c["device_rng"] else "inj", c["seed"], extra)
 
 
 def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
     """c: dict(kind, ncars, K, T, N, B, split, est, device_rng, seed).  Returns (status, messages): status in {"ok", "fail", "refused"}."""
     kind, ncars, K, T, N, B = c["kind"], c["ncars"], c["K"], c["T"], c["N"], c["B"]
     est, device_rng, seed = c["est"], c["device_rng"], c["seed"]
+    lam, alpha, lam_ais, elite, cma_sigma = c.get("lam", 10.0), c.get("alpha", 1.0), c.get("lam_ais", 20.0), c.get("elite", 0.8), c.get("cma_sigma", 0.75)
     cs = 2 * ncars * T
     cov = np.tile([0.0625, 0.1], ncars)
     tag = tag_of(c)
     try:
-        eng = Engine("car", ncars, kind, K, T, batch=B, lam=10.0, ais_its=N, lam_ais=20.0, elite_threshold=0.8, sigma_est=est, cma_sigma=0.75,
+        eng = Engine("car", ncars, kind, K, T, batch=B, lam=lam, alpha=alpha, ais_its=N, lam_ais=lam_ais, elite_threshold=elite, sigma_est=est, cma_sigma=cma_sigma,
                      cov=cov, track=track, seed=seed)
     except MPOPISError as e:
         return "refused", ["create refused: %s %s" % (tag, e)]
@@ -48,14 +50,14 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
                 for _ in range(int(rng.integers(1, 16))):      # the sub-step and the reference's sign(Vx) chatter (src/envs/car_racing.jl:311) from the start state on
                     e.step(np.clip(np.tile([0.0, -0.7], ncars) + 0.2 * rng.standard_normal(2 * ncars), -1, 1))
             envs.append(e)
-            pols.append(O.OraclePolicy(kind, e, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0, elite_threshold=0.8,
-                                       sigma_est=est, cma_sigma=0.75, nthreads=oracle_threads))
+            pols.append(O.OraclePolicy(kind, e, K, T, lam=lam, alpha=alpha, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=lam_ais, elite_threshold=elite,
+                                       sigma_est=est, cma_sigma=cma_sigma, nthreads=oracle_threads))
         eng.set_state(np.stack([e.state for e in envs]))
 
         def oracle_self_distance(b, U_before, Zb, dib, dub, ref):
             """the oracle against itself, pol.U nudged by 1e-13 relative, same state and draws: (control, U) distance = the policy's own conditioning"""
-            p2 = O.OraclePolicy(kind, envs[b], K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=20.0, elite_threshold=0.8,
-                                sigma_est=est, cma_sigma=0.75, nthreads=oracle_threads)
+            p2 = O.OraclePolicy(kind, envs[b], K, T, lam=lam, alpha=alpha, U0=np.zeros(2 * ncars), cov=cov, N=N, lam_ais=lam_ais, elite_threshold=elite,
+                                sigma_est=est, cma_sigma=cma_sigma, nthreads=oracle_threads)
             p2.U = U_before * (1.0 + 1e-13)
             r2 = p2(envs[b], Zb, dib, dub)
             if r2["status"] != 0:
@@ -91,9 +93,15 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
             for b in range(B):
                 r = refs[b]
                 rel = np.abs(got["cost"][b] - r["cost"]) / (np.abs(r["cost"]) + 1e-9)
-                nbad = int((rel > 1e-7).sum())
+                # alpha < 1 puts gamma U_orig' Σ'^-1 (V - U_orig) into every cost (:272): under the Σ-adapting policies Σ' is a K-sample scatter + 1e-8 I with
+                # cond up to 1e8, and the engine's triangular solves and the oracle's explicit inverse differ by cond * eps on that term -- measured 1e-7 ... 7e-6
+                # on the cost with the controls at 1e-11 (FUZZ_WILD): there the cost is held to the north star's 1e-5, not to 1e-7
+                nbad = int((rel > (1e-7 if alpha == 1.0 else 1e-5)).sum())
                 ea = float(np.abs(got["control"][b] - r["control"]).max())
-                eu = float(np.abs(U[b] - pols[b].U).max())
+                # pol.U relative to its own size: under :cmamppi with a large step factor the step size sigma runs away (every control saturates at the bounds, the
+                # costs stop depending on the mean) and |pol.U| grows to 1e2 ... 1e4 -- an absolute 1e-5 there asks for 1e-9 relative after a 10^3 amplification
+                uscale = max(1.0, float(np.abs(pols[b].U).max()))
+                eu = float(np.abs(U[b] - pols[b].U).max()) / uscale
                 idx_ok = True
                 if kind == "pmcmppi" and r["iters_run"] > 1:
                     n_it = r["iters_run"]
@@ -101,6 +109,8 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
                 # a slot that starts at (or near) a standstill: most of its rollouts chatter, their 50-step costs differ between any two evaluation
                 # orders (tests/test_gpu_standstill.py: 6-14 % of them, by up to 1e-1); what is held there is the north star's bound on the control
                 allow, tol = (max(2, ncars * K // 4), 1e-5) if braked[b] else (max(2, ncars * K // 200), 1e-6)
+                if alpha != 1.0:
+                    tol = 1e-5                                   # (the Σ'^-1 term above perturbs the weights at 1e-7: controls measured up to 2.6e-6 -- the north star's bound holds)
                 bad = got["iters_run"][b] != r["iters_run"] or nbad > allow or ea > tol or eu > 10 * tol or not idx_ok
                 # (never for the non-adaptive policies: with N = 1 nothing feeds on perturbed weights, the 1e-5 on the control holds as it stands)
                 if bad and braked[b] and got["iters_run"][b] == r["iters_run"] and kind not in ("mppi", "gmppi") and nbad <= allow and idx_ok:
@@ -113,8 +123,8 @@ def run_case(O, Engine, MPOPISError, track, c, rng, steps=2, oracle_threads=8):
                         if len(notes) < 3:
                             notes.append(msgs_note)
                 if bad:
-                    msgs.append("FAIL %s step %d slot %d iters %d %d cost-bad %d max rel %.2e ctrl %.2e U %.2e idx %s" % (
-                        tag, step, b, got["iters_run"][b], r["iters_run"], nbad, rel.max(), ea, eu, idx_ok))
+                    msgs.append("FAIL %s step %d slot %d iters %d %d cost-bad %d max rel %.2e ctrl %.2e U %.2e (|U| %.1e) idx %s" % (
+                        tag, step, b, got["iters_run"][b], r["iters_run"], nbad, rel.max(), ea, eu, uscale, idx_ok))
             if msgs:
                 break
     finally:
