@@ -136,3 +136,43 @@ def test_mountaincar_step_and_reward_match_the_oracle(shim, oracle):
                 done_seen += 1
                 break
     assert done_seen >= 5
+
+
+def test_model_step_with_random_car_parameters(shim, oracle):
+    """mpopis_set_env_params takes any CarRacingEnvParams / dt / δt (car_racing.jl:2-21,33-34): the reformulated step (hoisted tyre constants, carried sin / cos,
+    small-angle rotations with a library path beyond 1/32 rad, the 2-per-trip sub-step loop) against the literal step under RANDOM parameters -- masses, axle
+    geometry, tyre stiffness and friction, steering limits and rates up to the library path, brake / drive splits, slip limits, 1 ... 20 sub-steps incl. odd
+    counts -- in all five state regimes."""
+    rng = np.random.default_rng(77)
+    base = oracle.car_default_params()
+    worst, n_total = 0.0, 0
+    for trial in range(300):
+        p = base.copy()
+        p[0] *= rng.uniform(0.6, 1.6); p[1] *= rng.uniform(0.6, 1.6)                    # m, Izz
+        p[2] *= rng.uniform(0.5, 1.5)                                                    # h
+        p[3] *= rng.uniform(0.8, 1.25); p[4] *= rng.uniform(0.8, 1.25)                   # lf, lr
+        p[5] *= rng.uniform(0.0, 2.0); p[6] *= rng.uniform(0.0, 2.0)                     # CD0, CD1
+        p[7] *= rng.uniform(0.5, 1.8); p[8] *= rng.uniform(0.5, 1.8)                     # Caf, Car
+        p[9] = rng.uniform(0.4, 1.2); p[10] = rng.uniform(0.4, 1.2)                      # mu_f, mu_r
+        p[11] = np.deg2rad(rng.uniform(10.0, 45.0))                                      # delta_max
+        p[12] = np.deg2rad(rng.choice([30.0, 90.0, 150.0, 400.0, 900.0]))                # delta_dot_max (the last two: beyond the small-angle range per sub-step)
+        p[13] *= rng.uniform(0.5, 1.5); p[14] *= rng.uniform(0.5, 1.5)                   # Fx_max, Fx_min
+        p[15] = rng.uniform(0.3, 0.9); p[16] = rng.uniform(0.0, 1.0)                     # lambda_brake, lambda_drive
+        p[17] = np.deg2rad(rng.uniform(15.0, 80.0))                                      # beta_limit
+        nsub = int(rng.choice([1, 2, 3, 5, 7, 10, 13, 20]))
+        p[19] = float(rng.choice([0.005, 0.01, 0.02])); p[18] = nsub * p[19]             # delta_t, dt
+        for regime in ("driving", "crawling", "stopped", "backwards", "spinning"):
+            S = _states(rng, 6, regime)
+            S[:, 6] = rng.uniform(-0.9, 0.9, 6) * p[11]                                  # steering angle inside its limits
+            A = rng.uniform(-1, 1, (6, 2))
+            for i in range(6):
+                ref = oracle.car_step(p, S[i], A[i])
+                got = S[i].copy()
+                shim.shim_car_action_step(p.ctypes.data_as(dp), got.ctypes.data_as(dp), float(A[i, 0]), float(A[i, 1]))
+                d = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+                d[2] = min(d[2], abs(abs(got[2] - ref[2]) - 2 * np.pi))
+                if d.max() > 1e-9 and regime in ("crawling", "stopped"):                 # sign(Vx) decided within rounding of zero (see above)
+                    continue
+                worst = max(worst, float(d.max())); n_total += 1
+    print("\n[dynamics shim] random parameters: worst relative state deviation %.2e over %d steps" % (worst, n_total))
+    assert worst < 1e-10 and n_total > 8500
