@@ -117,3 +117,52 @@ def test_nan_control_in_the_scalar_action_envs(oracle, env_kind):
     pol = oracle.OraclePolicy("gmppi", env, K, T, lam=0.1, U0=np.zeros(1), cov=[1.5])
     pol.U = U[0]
     assert pol(env, np.random.default_rng(0).standard_normal((1, K, T)))["status"] == -3
+
+
+@pytest.mark.parametrize("kind,ncars,cov,lam,N", [("gmppi", 1, [1.0, 1.0], 1e4, 1), ("gmppi", 3, [0.6, 0.8], 1e4, 1), ("musigmaaismppi", 2, [0.5, 0.7], 1e3, 3),
+                                               ("cemppi", 1, [0.8, 0.9], 1e4, 3)])
+def test_run_trials_bookkeeping_when_things_go_wrong(oracle, track, kind, ncars, cov, lam, N):
+    """The trial loop's statistics (src/examples/car_example.jl:238-302) in closed loops that do NOT go well: wide proposals and a large lambda make the
+    controller drive erratically, cars leave the track, exceed the slip-angle limit and (multi-car) run into each other -- the counters of track / beta / crash
+    violations, the per-car means and maxima and the early termination (`T_viol > 10 || beta_viol > 50`, :277-279) must match the oracle's restatement field
+    by field, and so must the actions step by step (same Philox streams).  The calm closed loops of tests/test_gpu_parity.py never enter these branches."""
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    K, T, B, steps, seed = 96, 12, 3, 70, 4100
+    covf = np.tile(cov, ncars)
+    eng = Engine("car", ncars, kind, K, T, batch=B, lam=lam, ais_its=N, lam_ais=lam, elite_threshold=0.8, cov=covf, track=track, seed=seed)
+    # start states that are already in trouble: near the lane's edge heading outwards, sliding (slip angle beyond the limit), the cars of a multi-car env
+    # within collision distance of each other
+    tx, ty, tw = track
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 8 * ncars))
+    for b in range(B):
+        j = int(rng.integers(0, len(tx)))
+        jn = (j + 1) % len(tx)
+        head = np.arctan2(ty[jn] - ty[j], tx[jn] - tx[j])
+        nrm = np.array([-np.sin(head), np.cos(head)])
+        for c in range(ncars):
+            off = (0.6 + 0.25 * b) * 0.5 * tw[j] * (1 if (b + c) % 2 else -1)          # 0.3 ... 0.55 lane widths off the centre line
+            pos = np.array([tx[j], ty[j]]) + off * nrm + 2.5 * c * np.array([np.cos(head), np.sin(head)])
+            x0[b, 8 * c:8 * c + 8] = [pos[0], pos[1], head + 0.5 * np.sign(off), 9.0 + 3 * b, 8.0 * np.sign(off) * (1 if b != 1 else 0.3), 0.4, 0.1, 0.0]
+    eng.set_state(x0)
+    rec, acts = eng.run_trials(num_steps=steps, laps=2, log_actions=True)
+    eng.close()
+    viol = np.zeros(3)
+    for b in range(B):
+        env = oracle.OracleEnv("car", ncars, track=track)
+        env.state = x0[b]
+        pol = oracle.OraclePolicy(kind, env, K, T, lam=lam, U0=np.zeros(2 * ncars), cov=covf, N=N, lam_ais=lam, elite_threshold=0.8, nthreads=8)
+        r = pol.run_trial(env, seed + b + 1, num_steps=steps, laps=2, log_actions=True)
+        assert r["status"] == 0 and rec[b, 15] == 0
+        n = int(r["steps"])
+        assert rec[b, 1] == r["steps"], (rec[b, 1], r["steps"])                      # incl. the early termination on violations
+        assert rec[b, 14] == r["rollouts"]
+        assert np.max(np.abs(acts[b][:n] - r["actions"][:n])) < 1e-6
+        ref = np.array([r["rew"], r["steps"], r["rew_per_step"]] + r["lap_t"] + [r["mean_v"], r["max_v"], r["mean_beta"], r["max_beta"], r["beta_viol"], r["trk_viol"], r["crash_viol"]])
+        assert np.array_equal(rec[b, 11:14], ref[11:14]), (rec[b, 11:14], ref[11:14])  # violation counters: exact
+        assert np.max(np.abs(rec[b, :11] - ref[:11]) / np.maximum(1.0, np.abs(ref[:11]))) < 1e-6, (rec[b, :11], ref[:11])
+        viol += ref[11:14]
+    print("\n[run_trials, rough] %s cars=%d: beta / track / crash violations over %d trials: %s" % (kind, ncars, B, viol))
+    assert viol.sum() > 0                                                            # the case really enters the violation branches
