@@ -166,3 +166,36 @@ def test_run_trials_bookkeeping_when_things_go_wrong(oracle, track, kind, ncars,
         viol += ref[11:14]
     print("\n[run_trials, rough] %s cars=%d: beta / track / crash violations over %d trials: %s" % (kind, ncars, B, viol))
     assert viol.sum() > 0                                                            # the case really enters the violation branches
+
+
+@pytest.mark.parametrize("ncars", [1, 2])
+def test_run_trials_lap_counting_and_lap_termination(oracle, track, ncars):
+    """Lap bookkeeping (car_example.jl:273-279): a lap is counted when the rearmost car's y crosses 0 upwards within 15 m of the origin, its step number goes to
+    lap_t, and the trial ends after `laps` laps.  Start states a few metres before the line (the calm 30-step loops elsewhere never get there): engine and
+    oracle must count the same laps at the same steps and stop at the same step."""
+    from mpopis_amd import build
+    build.build()
+    from mpopis_amd.engine import Engine
+    K, T, B, seed = 128, 12, 3, 808
+    cov = np.tile([0.0625, 0.1], ncars)
+    x0 = np.zeros((B, 8 * ncars))
+    for b in range(B):
+        for c in range(ncars):
+            x0[b, 8 * c:8 * c + 8] = [3.0 * c - 1.0, -2.0 - 3.0 * b - 1.5 * c, np.pi / 2, 10.0 + b, 0.0, 0.0, 0.0, 0.0]     # heading +y, 2 ... 11 m before the line
+    for laps in (1, 2):
+        eng = Engine("car", ncars, "gmppi", K, T, batch=B, lam=10.0, cov=cov, track=track, seed=seed)
+        eng.set_state(x0)
+        rec, acts = eng.run_trials(num_steps=14, laps=laps, log_actions=True)
+        eng.close()
+        for b in range(B):
+            env = oracle.OracleEnv("car", ncars, track=track)
+            env.state = x0[b]
+            pol = oracle.OraclePolicy("gmppi", env, K, T, lam=10.0, U0=np.zeros(2 * ncars), cov=cov, nthreads=8)
+            r = pol.run_trial(env, seed + b + 1, num_steps=14, laps=laps, log_actions=True)
+            assert rec[b, 1] == r["steps"], (laps, b, rec[b, 1], r["steps"])
+            assert list(rec[b, 3:7]) == list(r["lap_t"]), (laps, b, rec[b, 3:7], r["lap_t"])
+            assert r["lap_t"][0] > 0                                              # the line really was crossed
+            if laps == 1:
+                assert r["steps"] < 14                                            # ... and one lap ended the trial early
+            n = int(r["steps"])
+            assert np.max(np.abs(acts[b][:n] - r["actions"][:n])) < 1e-6
