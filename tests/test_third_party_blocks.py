@@ -113,3 +113,22 @@ def test_alias_table_is_a_valid_table_of_the_weights(oracle):
         np.add.at(p, al, 1.0 - acc)
         assert np.max(np.abs(p / K - w)) < 1e-13
         assert np.all((acc >= 0) & (acc <= 1 + 1e-12)) and np.all((al >= 0) & (al < K))
+
+
+def test_host_summary_statistics_match_the_oracle_and_numpy(oracle):
+    """The harness' summary table (car_example.jl:328-410: AVE / STD / MED / L95 / U95 / MIN / MAX; quantile_ci = example_utils.jl:2-10) in the Python host mirror
+    against the oracle's restatement and plain NumPy, on samples of 1 ... 64 trials (the order-statistic indices j, k clamp at the ends for small n)."""
+    from mpopis_amd.examples import quantile_ci, _summary
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 3, 5, 8, 16, 33, 64):
+        x = rng.normal(10.0, 3.0, n)
+        lo, med, hi = quantile_ci(x)
+        olo, omed, ohi = oracle.quantile_ci(x)
+        assert (lo, hi) == (olo, ohi) and abs(med - omed) < 1e-14
+        assert lo <= med <= hi and lo in x and hi in x
+        rows = rng.normal(0.0, 1.0, (n, 4))
+        s = _summary(rows)
+        assert np.allclose(s["AVE"], rows.mean(0)) and np.allclose(s["MIN"], rows.min(0)) and np.allclose(s["MAX"], rows.max(0))
+        assert np.allclose(s["MED"], np.median(rows, axis=0))
+        if n > 1:
+            assert np.allclose(s["STD"], rows.std(0, ddof=1))                      # Julia's std is the corrected one
