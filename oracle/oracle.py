@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmpopis_oracle.so")
+_LIB_PATH = os.environ.get("MPOPIS_ORACLE_LIB") or os.path.join(_HERE, "libmpopis_oracle.so")      # (override: the sanitizer build of tests/dev/oracle_sanitizers.sh)
 
 ENV_MOUNTAINCAR, ENV_CAR, ENV_CARTPOLE = 0, 1, 2
 POL = dict(mppi=0, gmppi=1, imppi=2, cemppi=3, cmamppi=4, muaismppi=5, musigmaaismppi=6, pmcmppi=7)
@@ -19,6 +19,8 @@ CP_N, MP_N = 20, 8
 
 
 def build(force=False):
+    if os.environ.get("MPOPIS_ORACLE_LIB"):
+        return _LIB_PATH
     src = os.path.join(_HERE, "mpopis_oracle.c")
     hdr = os.path.join(_HERE, "mpopis_oracle.h")
     if (not force and os.path.exists(_LIB_PATH)
