@@ -47,4 +47,7 @@ for case in range(ncases):
     for m in msgs:
         print(m)
     bad += st == "fail"
+    if st == "fail" and os.environ.get("FUZZ_DUMP"):
+        print("stopped at case index %d (dump: %s)" % (case, os.environ["FUZZ_DUMP"]))
+        break
 print("%d cases, %d failed, %.0fs" % (ncases, bad, time.time() - t0))
